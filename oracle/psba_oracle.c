@@ -1,0 +1,521 @@
+/*
+ * psba_oracle.c -- CPU restatement (plain C, fp64, single thread) of the eglrp/PSBA
+ * Schur-complement bundle-adjustment normal-equations path and its Levenberg-Marquardt
+ * caller.  TEST INFRASTRUCTURE ONLY -- see psba_oracle.h for the rules and the parity pin.
+ *
+ * Build with -O2 -ffp-contract=off (oracle/Makefile) so that sums are evaluated in the
+ * written order without fused multiply-adds.
+ */
+#include "psba_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define CNP 6
+#define PNP 3
+#define MNP 2
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *xmalloc(size_t n) {
+  void *p = malloc(n ? n : 1);
+  if (!p) {
+    fprintf(stderr, "psba_oracle: out of memory (%zu bytes)\n", n);
+    abort();
+  }
+  return p;
+}
+
+/* ---- camera model --------------------------------------------------------------------
+ * q_l = (sqrt(1-|v|^2), v); q = q_l (x) q0 (Hamilton, local rotation on the left),
+ * CL_files/compute_exQT.cl:36-49.  q = (q[0]; q[1..3]) scalar first. */
+static void compose_quat(const double *q0, const double *v, double *q) {
+  double si = sqrt(1 - v[0] * v[0] - v[1] * v[1] - v[2] * v[2]);
+  double s0 = q0[0], a1 = q0[1], a2 = q0[2], a3 = q0[3];
+  q[0] = si * s0 - (a1 * v[0] + a2 * v[1] + a3 * v[2]);
+  q[1] = s0 * v[0] + si * a1 + a3 * v[1] - a2 * v[2];
+  q[2] = s0 * v[1] + si * a2 + a1 * v[2] - a3 * v[0];
+  q[3] = s0 * v[2] + si * a3 + a2 * v[0] - a1 * v[1];
+}
+
+static void cross3(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* rotate M by the quaternion sandwich q (0,M) q*, the form the reference expands
+ * (CL_files/compute_exQT.cl:59-65): with u = vec(q), w = s M + u x M,
+ * R M = (u.M) u + s w + u x w. */
+static void quat_rotate(const double *q, const double *M, double *out) {
+  const double s = q[0];
+  const double *u = q + 1;
+  double uxM[3], w[3], uxw[3];
+  double udM = u[0] * M[0] + u[1] * M[1] + u[2] * M[2];
+  cross3(u, M, uxM);
+  for (int c = 0; c < 3; c++) w[c] = s * M[c] + uxM[c];
+  cross3(u, w, uxw);
+  for (int c = 0; c < 3; c++) out[c] = udM * u[c] + s * w[c] + uxw[c];
+}
+
+/* x = (fu Px + s Py + u0 Pz)/Pz ; y = (fu ar Py + v0 Pz)/Pz, K = (fu,u0,v0,ar,s)
+ * CL_files/compute_exQT.cl:66-69. */
+static void project(const double *K, const double *P, double *xy) {
+  double inv = 1 / P[2];
+  xy[0] = (K[0] * P[0] + K[4] * P[1] + K[1] * P[2]) * inv;
+  xy[1] = (K[0] * K[3] * P[1] + K[2] * P[2]) * inv;
+}
+
+void orc_compute_exQT(int nO, const double *K, const double *impts, const double *initrot,
+                      const double *cams, const double *pts, const int *iidx, const int *jidx,
+                      double *ex) {
+  for (int idx = 0; idx < nO; idx++) {
+    int i = iidx[idx], j = jidx[idx];
+    double q[4], P[3], xy[2];
+    compose_quat(initrot + 4 * j, cams + 6 * j, q);
+    quat_rotate(q, pts + 3 * i, P);
+    for (int c = 0; c < 3; c++) P[c] += cams[6 * j + 3 + c];
+    project(K + 5 * j, P, xy);
+    ex[2 * idx] = impts[2 * idx] - xy[0];
+    ex[2 * idx + 1] = impts[2 * idx + 1] - xy[1];
+  }
+}
+
+void orc_compute_jacobiQT(int nO, const double *K, const double *initrot, const double *cams,
+                          const double *pts, const int *iidx, const int *jidx, double *JA,
+                          double *JB) {
+  for (int idx = 0; idx < nO; idx++) {
+    int i = iidx[idx], j = jidx[idx];
+    const double *Kj = K + 5 * j, *q0 = initrot + 4 * j, *v = cams + 6 * j, *M = pts + 3 * i;
+    double q[4], P[3], xy[2], D[2][3];
+    compose_quat(q0, v, q);
+    quat_rotate(q, M, P);
+    for (int c = 0; c < 3; c++) P[c] += v[3 + c];
+    project(Kj, P, xy);
+    double inv = 1 / P[2];
+    /* D = d(x,y)/dP */
+    D[0][0] = Kj[0] * inv;
+    D[0][1] = Kj[4] * inv;
+    D[0][2] = (Kj[1] - xy[0]) * inv;
+    D[1][0] = 0.0;
+    D[1][1] = Kj[0] * Kj[3] * inv;
+    D[1][2] = (Kj[2] - xy[1]) * inv;
+
+    double *A = JA + 12 * idx, *B = JB + 6 * idx;
+    const double s = q[0];
+    const double *u = q + 1;
+
+    /* B = D * dP/dM ; P is linear in M, column m of dP/dM is the rotation of e_m */
+    for (int m = 0; m < 3; m++) {
+      double e[3] = {0, 0, 0}, col[3];
+      e[m] = 1.0;
+      quat_rotate(q, e, col);
+      B[m] = D[0][0] * col[0] + D[0][1] * col[1] + D[0][2] * col[2];
+      B[3 + m] = D[1][0] * col[0] + D[1][1] * col[1] + D[1][2] * col[2];
+    }
+
+    /* A[:,0..2] = D * dP/dv_k.  dq_l/dv_k = (-v_k/s_l, e_k); dq = dq_l (x) q0. */
+    double si = sqrt(1 - v[0] * v[0] - v[1] * v[1] - v[2] * v[2]);
+    double uxM[3], w[3];
+    double udM = u[0] * M[0] + u[1] * M[1] + u[2] * M[2];
+    cross3(u, M, uxM);
+    for (int c = 0; c < 3; c++) w[c] = s * M[c] + uxM[c];
+    for (int k = 0; k < 3; k++) {
+      double dsl = -v[k] / si;
+      double e[3] = {0, 0, 0}, exv0[3], du[3], duxM[3], dw[3], duxw[3], uxdw[3], dP[3];
+      e[k] = 1.0;
+      cross3(e, q0 + 1, exv0);
+      double ds = dsl * q0[0] - q0[1 + k];
+      for (int c = 0; c < 3; c++) du[c] = q0[0] * e[c] + dsl * q0[1 + c] + exv0[c];
+      cross3(du, M, duxM);
+      for (int c = 0; c < 3; c++) dw[c] = ds * M[c] + duxM[c];
+      cross3(du, w, duxw);
+      cross3(u, dw, uxdw);
+      double dudM = du[0] * M[0] + du[1] * M[1] + du[2] * M[2];
+      for (int c = 0; c < 3; c++)
+        dP[c] = dudM * u[c] + udM * du[c] + ds * w[c] + s * dw[c] + duxw[c] + uxdw[c];
+      A[k] = D[0][0] * dP[0] + D[0][1] * dP[1] + D[0][2] * dP[2];
+      A[6 + k] = D[1][0] * dP[0] + D[1][1] * dP[1] + D[1][2] * dP[2];
+    }
+    /* A[:,3..5] = D (translation) */
+    for (int c = 0; c < 3; c++) {
+      A[3 + c] = D[0][c];
+      A[9 + c] = D[1][c];
+    }
+  }
+}
+
+void orc_compute_U(int nC, int nO, const double *JA, const int *jidx, double coeff, double *U,
+                   double *UVdiag) {
+  memset(U, 0, sizeof(double) * 36 * (size_t)nC);
+  /* observations are visited in point-ascending order, so each U_j(r,c) is summed over i
+   * ascending exactly as compute_U.cl:22-29 does */
+  for (int idx = 0; idx < nO; idx++) {
+    const double *A = JA + 12 * idx;
+    double *Uj = U + 36 * jidx[idx];
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) Uj[6 * r + c] = Uj[6 * r + c] + A[r] * A[c] + A[6 + r] * A[6 + c];
+  }
+  for (int j = 0; j < nC; j++)
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        double sum = coeff * U[36 * j + 6 * r + c];
+        U[36 * j + 6 * r + c] = sum;
+        if (r == c) UVdiag[6 * j + r] = sum;
+      }
+}
+
+void orc_compute_V(int nC, int nP, int nO, const double *JB, const int *iidx, double coeff,
+                   double *V, double *UVdiag) {
+  memset(V, 0, sizeof(double) * 9 * (size_t)nP);
+  for (int idx = 0; idx < nO; idx++) {
+    const double *B = JB + 6 * idx;
+    double *Vi = V + 9 * iidx[idx];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Vi[3 * r + c] = Vi[3 * r + c] + B[r] * B[c] + B[3 + r] * B[3 + c];
+  }
+  for (int i = 0; i < nP; i++)
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double sum = coeff * V[9 * i + 3 * r + c];
+        V[9 * i + 3 * r + c] = sum;
+        if (r == c) UVdiag[6 * nC + 3 * i + r] = sum;
+      }
+}
+
+void orc_compute_Wblks(int nO, const double *JA, const double *JB, double coeff, double *W) {
+  for (int idx = 0; idx < nO; idx++) {
+    const double *A = JA + 12 * idx, *B = JB + 6 * idx;
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 3; c++) W[18 * idx + 3 * r + c] = coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+  }
+}
+
+void orc_compute_g(int nC, int nP, int nO, double coeff, const double *JA, const double *JB,
+                   const int *iidx, const int *jidx, const double *ex, double *g) {
+  int nA = 6 * nC, nT = 6 * nC + 3 * nP;
+  memset(g, 0, sizeof(double) * (size_t)nT);
+  for (int idx = 0; idx < nO; idx++) {
+    const double *A = JA + 12 * idx, *B = JB + 6 * idx;
+    double e0 = ex[2 * idx], e1 = ex[2 * idx + 1];
+    double *ga = g + 6 * jidx[idx], *gb = g + nA + 3 * iidx[idx];
+    for (int k = 0; k < 6; k++) ga[k] = ga[k] + A[k] * e0 + A[6 + k] * e1;
+    for (int k = 0; k < 3; k++) gb[k] = gb[k] + B[k] * e0 + B[3 + k] * e1;
+  }
+  for (int t = 0; t < nT; t++) g[t] = coeff * g[t];
+}
+
+double orc_maxElmOfUV(int nT, const double *UVdiag) {
+  double m = UVdiag[0];
+  for (int t = 1; t < nT; t++)
+    if (UVdiag[t] > m) m = UVdiag[t];
+  return m;
+}
+
+void orc_update_UV(int nC, int nP, double *U, double *V, double mu) {
+  for (int j = 0; j < nC; j++)
+    for (int r = 0; r < 6; r++) U[36 * j + 7 * r] = U[36 * j + 7 * r] + mu;
+  for (int i = 0; i < nP; i++)
+    for (int r = 0; r < 3; r++) V[9 * i + 4 * r] = V[9 * i + 4 * r] + mu;
+}
+
+void orc_restore_UVdiag(int nC, int nP, double *U, double *V, const double *UVdiag) {
+  for (int j = 0; j < nC; j++)
+    for (int r = 0; r < 6; r++) U[36 * j + 7 * r] = UVdiag[6 * j + r];
+  for (int i = 0; i < nP; i++)
+    for (int r = 0; r < 3; r++) V[9 * i + 4 * r] = UVdiag[6 * nC + 3 * i + r];
+}
+
+double orc_compute_Vinv(int nP, const double *V, double *Vinv) {
+  double ret = 0.0;
+  for (int i = 0; i < nP; i++) {
+    const double *a = V + 9 * i;
+    double a11 = a[0], a12 = a[1], a13 = a[2], a22 = a[4], a23 = a[5], a33 = a[8];
+    /* T = -det, compute_Vinv.cl:29 */
+    double T = (a33 * a12 * a12 - 2 * a12 * a13 * a23 + a22 * a13 * a13 + a11 * a23 * a23 -
+                a11 * a22 * a33);
+    if (fabs(T) < 1e-16) ret = 1.0;
+    double *o = Vinv + 9 * i;
+    o[0] = -(-a23 * a23 + a22 * a33) / T;
+    o[3] = -(a13 * a23 - a12 * a33) / T;
+    o[4] = -(-a13 * a13 + a11 * a33) / T;
+    o[6] = -(a12 * a23 - a13 * a22) / T;
+    o[7] = -(a12 * a13 - a11 * a23) / T;
+    o[8] = -(-a12 * a12 + a11 * a22) / T;
+    o[1] = o[3];
+    o[2] = o[6];
+    o[5] = o[7];
+  }
+  return ret;
+}
+
+void orc_compute_Yblks(int nO, const int *iidx, const double *W, const double *Vinv, double *Y) {
+  for (int idx = 0; idx < nO; idx++) {
+    const double *Vi = Vinv + 9 * iidx[idx];
+    for (int r = 0; r < 6; r++) {
+      const double *w = W + 18 * idx + 3 * r;
+      for (int c = 0; c < 3; c++) Y[18 * idx + 3 * r + c] = w[0] * Vi[c] + w[1] * Vi[3 + c] + w[2] * Vi[6 + c];
+    }
+  }
+}
+
+void orc_compute_S(int nC, int nP, int nO, const int *iidx, const int *jidx, const double *U,
+                   const double *Y, const double *W, double *S) {
+  int nA = 6 * nC;
+  (void)nP;
+  memset(S, 0, sizeof(double) * (size_t)nA * nA);
+  int a0 = 0;
+  while (a0 < nO) {
+    int a1 = a0;
+    while (a1 < nO && iidx[a1] == iidx[a0]) a1++;
+    for (int a = a0; a < a1; a++)
+      for (int b = a0; b < a1; b++) {
+        int k = jidx[a], l = jidx[b];
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) {
+            const double *y = Y + 18 * a + 3 * r, *w = W + 18 * b + 3 * c;
+            S[(size_t)(6 * k + r) * nA + 6 * l + c] += y[0] * w[0] + y[1] * w[1] + y[2] * w[2];
+          }
+      }
+    a0 = a1;
+  }
+  for (int k = 0; k < nC; k++)
+    for (int l = 0; l < nC; l++)
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+          size_t at = (size_t)(6 * k + r) * nA + 6 * l + c;
+          S[at] = (k == l) ? U[36 * k + 6 * r + c] - S[at] : -S[at];
+        }
+}
+
+void orc_compute_ea(int nC, int nP, int nO, const int *iidx, const int *jidx, const double *Y,
+                    const double *g, double *eab) {
+  int nA = 6 * nC;
+  (void)nP;
+  double *sum = (double *)xmalloc(sizeof(double) * (size_t)nA);
+  memset(sum, 0, sizeof(double) * (size_t)nA);
+  for (int idx = 0; idx < nO; idx++) {
+    const double *gb = g + nA + 3 * iidx[idx];
+    for (int r = 0; r < 6; r++) {
+      const double *y = Y + 18 * idx + 3 * r;
+      sum[6 * jidx[idx] + r] = sum[6 * jidx[idx] + r] + y[0] * gb[0] + y[1] * gb[1] + y[2] * gb[2];
+    }
+  }
+  for (int t = 0; t < nA; t++) eab[t] = g[t] - sum[t];
+  free(sum);
+}
+
+double orc_chol_solve(int n, double *S, const double *ea, double *dpa) {
+  /* in-place lower Cholesky, row-major */
+  for (int j = 0; j < n; j++) {
+    double d = S[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= S[(size_t)j * n + k] * S[(size_t)j * n + k];
+    double l = sqrt(d);
+    if (!(d > 0.0) || !isfinite(l)) return 1.0;
+    S[(size_t)j * n + j] = l;
+    for (int i = j + 1; i < n; i++) {
+      double t = S[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) t -= S[(size_t)i * n + k] * S[(size_t)j * n + k];
+      t = t / l;
+      if (!isfinite(t)) return 1.0;
+      S[(size_t)i * n + j] = t;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    double t = ea[i];
+    for (int k = 0; k < i; k++) t -= S[(size_t)i * n + k] * dpa[k];
+    dpa[i] = t / S[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double t = dpa[i];
+    for (int k = i + 1; k < n; k++) t -= S[(size_t)k * n + i] * dpa[k];
+    dpa[i] = t / S[(size_t)i * n + i];
+  }
+  for (int i = 0; i < n; i++)
+    if (!isfinite(dpa[i])) return 1.0;
+  return 0.0;
+}
+
+void orc_compute_eb(int nC, int nP, int nO, const int *iidx, const int *jidx, const double *W,
+                    const double *dp, const double *g, double *eab) {
+  int nA = 6 * nC;
+  double *sum = (double *)xmalloc(sizeof(double) * 3 * (size_t)nP);
+  memset(sum, 0, sizeof(double) * 3 * (size_t)nP);
+  for (int idx = 0; idx < nO; idx++) {
+    const double *w = W + 18 * idx, *dpa = dp + 6 * jidx[idx];
+    double *s = sum + 3 * iidx[idx];
+    for (int c = 0; c < 3; c++)
+      for (int k = 0; k < 6; k++) s[c] = s[c] + w[3 * k + c] * dpa[k];
+  }
+  for (int t = 0; t < 3 * nP; t++) eab[nA + t] = g[nA + t] - sum[t];
+  free(sum);
+}
+
+void orc_compute_dpb(int nC, int nP, const double *Vinv, const double *eab, double *dp) {
+  int nA = 6 * nC;
+  for (int i = 0; i < nP; i++) {
+    const double *Vi = Vinv + 9 * i, *eb = eab + nA + 3 * i;
+    for (int r = 0; r < 3; r++) dp[nA + 3 * i + r] = Vi[3 * r] * eb[0] + Vi[3 * r + 1] * eb[1] + Vi[3 * r + 2] * eb[2];
+  }
+}
+
+void orc_compute_newp(int nA, int nB, const double *cams, const double *pts, const double *dp,
+                      double *newcams, double *newpts) {
+  for (int t = 0; t < nA; t++) newcams[t] = cams[t] + dp[t];
+  for (int t = 0; t < nB; t++) newpts[t] = pts[t] + dp[nA + t];
+}
+
+double orc_L2_sq(int n, const double *x) {
+  double sum = 0;
+  for (int i = 0; i < n; i++) sum += x[i] * x[i];
+  return sum;
+}
+
+int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
+               const double *initrot, double *cams, double *pts, const int *iidx,
+               const int *jidx, const orc_lm_opts *opts, orc_lm_result *res, double *log) {
+  const int nA = 6 * nC, nB = 3 * nP, nT = nA + nB;
+  const double STOP = 1e-12, EPS_SQ = 1e-12 * 1e-12; /* PSBA/psba.h:7-10 */
+  double *ex = xmalloc(sizeof(double) * 2 * (size_t)nO);
+  double *JA = xmalloc(sizeof(double) * 12 * (size_t)nO);
+  double *JB = xmalloc(sizeof(double) * 6 * (size_t)nO);
+  double *W = xmalloc(sizeof(double) * 18 * (size_t)nO);
+  double *Y = xmalloc(sizeof(double) * 18 * (size_t)nO);
+  double *U = xmalloc(sizeof(double) * 36 * (size_t)nC);
+  double *V = xmalloc(sizeof(double) * 9 * (size_t)nP);
+  double *Vinv = xmalloc(sizeof(double) * 9 * (size_t)nP);
+  double *UVdiag = xmalloc(sizeof(double) * (size_t)nT);
+  double *S = xmalloc(sizeof(double) * (size_t)nA * nA);
+  double *g = xmalloc(sizeof(double) * (size_t)nT);
+  double *eab = xmalloc(sizeof(double) * (size_t)nT);
+  double *dp = xmalloc(sizeof(double) * (size_t)nT);
+  double *newcams = xmalloc(sizeof(double) * (size_t)nA);
+  double *newpts = xmalloc(sizeof(double) * (size_t)nB);
+
+  memset(res, 0, sizeof(*res));
+  double mu = 0, rho, p_L2 = 0, dp_L2, ex_L2, new_ex_L2;
+  int nu = 2, first = 1, gooditer = 0, tries = 0, itno = 0, nlog = 0;
+  int flag = ORC_ITER_CONTINUE;
+  double t0;
+
+  t0 = now_s();
+  orc_compute_exQT(nO, K, impts, initrot, cams, pts, iidx, jidx, ex); /* levmar.cpp:93-95 */
+  ex_L2 = orc_L2_sq(2 * nO, ex);
+  res->t_cost += now_s() - t0;
+  res->init_err = ex_L2;
+
+  for (; itno < opts->max_iter && flag == ORC_ITER_CONTINUE; itno++) { /* levmar.cpp:100 */
+    t0 = now_s();
+    orc_compute_jacobiQT(nO, K, initrot, cams, pts, iidx, jidx, JA, JB); /* :103 */
+    orc_compute_U(nC, nO, JA, jidx, 1.0, U, UVdiag);                     /* :104 */
+    orc_compute_V(nC, nP, nO, JB, iidx, 1.0, V, UVdiag);                 /* :105 */
+    orc_compute_Wblks(nO, JA, JB, 1.0, W);                               /* :106 */
+    /* ex still holds the residual at the current parameters: the try loop is only left
+     * with an accepted step (whose residual was the last one evaluated) or by stopping. */
+    orc_compute_g(nC, nP, nO, 1.0, JA, JB, iidx, jidx, ex, g); /* :108 */
+    res->t_linearize += now_s() - t0;
+
+    if (first) { /* :114-120 */
+      mu = 1e-3 * orc_maxElmOfUV(nT, UVdiag);
+      res->mu0 = mu;
+      first = 0;
+      p_L2 = 1e+3;
+      nu = 2;
+    }
+    while (1) {
+      tries++;
+      t0 = now_s();
+      orc_update_UV(nC, nP, U, V, mu);                          /* :126 */
+      orc_compute_Vinv(nP, V, Vinv);                            /* :127 (return ignored) */
+      orc_compute_Yblks(nO, iidx, W, Vinv, Y);                  /* :128 */
+      orc_compute_S(nC, nP, nO, iidx, jidx, U, Y, W, S);        /* :130 */
+      orc_compute_ea(nC, nP, nO, iidx, jidx, Y, g, eab);        /* :131 */
+      res->t_schur += now_s() - t0;
+      t0 = now_s();
+      double ret = orc_chol_solve(nA, S, eab, dp);              /* :134-140 */
+      res->t_solve += now_s() - t0;
+      if (ret == 0.0) {
+        t0 = now_s();
+        orc_compute_eb(nC, nP, nO, iidx, jidx, W, dp, g, eab);  /* :151 */
+        orc_compute_dpb(nC, nP, Vinv, eab, dp);                 /* :155 */
+        dp_L2 = orc_L2_sq(nT, dp);                              /* :157 */
+        res->t_backsub += now_s() - t0;
+        if (dp_L2 < p_L2 * STOP * STOP) { /* :169-173 */
+          flag = ORC_ITER_DP_NO_CHANGE;
+          break;
+        }
+        if (dp_L2 >= (p_L2 + STOP) / EPS_SQ) { /* :174-179 */
+          flag = ORC_ITER_ERR;
+          break;
+        }
+        orc_restore_UVdiag(nC, nP, U, V, UVdiag);               /* :182 */
+        orc_compute_newp(nA, nB, cams, pts, dp, newcams, newpts); /* :185 */
+        t0 = now_s();
+        orc_compute_exQT(nO, K, impts, initrot, newcams, newpts, iidx, jidx, ex); /* :188 */
+        new_ex_L2 = orc_L2_sq(2 * nO, ex);                      /* :193 */
+        res->t_cost += now_s() - t0;
+        double sum = 0; /* compute_rho, :271-280 */
+        for (int t = 0; t < nT; t++) sum += dp[t] * (mu * dp[t] + g[t]);
+        rho = (ex_L2 - new_ex_L2) / sum;
+        if (opts->verbose)
+          printf("itno=%d\t\tErr=%.15E\t\trho=%f\t\tmu=%f\n", itno, new_ex_L2, rho, mu);
+        if (log && nlog < opts->log_cap) {
+          double *row = log + 5 * nlog++;
+          row[0] = itno; row[1] = new_ex_L2; row[2] = rho; row[3] = mu; row[4] = rho > 0;
+        }
+        if (rho > 0) { /* :200-223 */
+          double tmp = 2 * rho - 1;
+          tmp = 1.0 - tmp * tmp * tmp;
+          mu = mu * ((tmp >= (1.0 / 3.0)) ? tmp : (1.0 / 3.0));
+          nu = 2;
+          memcpy(cams, newcams, sizeof(double) * (size_t)nA); /* update_p :211 */
+          memcpy(pts, newpts, sizeof(double) * (size_t)nB);
+          p_L2 = 0; /* :212, one running sum over cams then points */
+          for (int t = 0; t < nA; t++) p_L2 += cams[t] * cams[t];
+          for (int t = 0; t < nB; t++) p_L2 += pts[t] * pts[t];
+          ex_L2 = new_ex_L2;
+          if (fabs(rho - 1) < (1.0 / 5.0)) {
+            gooditer++;
+            if (opts->tr_handoff && gooditer >= 5) {
+              flag = ORC_ITER_TURN_TO_TR;
+              break;
+            }
+          } else
+            gooditer = 0;
+          break;
+        }
+      } else { /* :227-233 */
+        gooditer = 0;
+        orc_restore_UVdiag(nC, nP, U, V, UVdiag);
+        if (log && nlog < opts->log_cap) {
+          double *row = log + 5 * nlog++;
+          row[0] = itno; row[1] = NAN; row[2] = NAN; row[3] = mu; row[4] = -1;
+        }
+      }
+      mu *= nu; /* :237-244 */
+      double nu2 = 2.0 * nu;
+      if (nu2 <= nu || nu2 > 1e9) {
+        flag = ORC_ITER_ERR;
+        break;
+      }
+      nu = (int)nu2;
+    }
+    if (ex_L2 <= STOP) flag = ORC_ITER_ERR_SMALL_ENOUGH; /* :247-248 */
+  }
+
+  res->flag = flag;
+  res->iters = itno;
+  res->tries = tries;
+  res->final_err = ex_L2;
+  res->n_log = nlog;
+  free(ex); free(JA); free(JB); free(W); free(Y); free(U); free(V); free(Vinv); free(UVdiag);
+  free(S); free(g); free(eab); free(dp); free(newcams); free(newpts);
+  return flag;
+}
