@@ -1,0 +1,218 @@
+/*
+ * psba_hip.h -- C ABI of the MI355X-native Schur-complement bundle-adjustment
+ * normal-equations path (drop-in for the operator layer of eglrp/PSBA).
+ *
+ * What it replaces (paths relative to the reference checkout):
+ *   PSBA/sba_func.h:10-138      the per-kernel host wrappers called by levmar()/trust_region()
+ *   PSBA/cl_spdinv.h:7-18       SPDinv / cholesky / trigMat_inv / trigMat_mul
+ *   PSBA/cl_linearalg.h:8-9     matVec_mul
+ *   PSBA/cl_psba.h:9-126        PSBA_struct, setup_cl, fill_initBuffer2, fill_idxBuffer,
+ *                               release_buffer
+ *   PSBA/misc.cpp:178-217       generate_idxs (dense blk_idx/comm3DIdx tables -> CSR inside)
+ *   PSBA/levmar.cpp:45-256      levmar() (restated over this ABI as psba_levmar)
+ *   PSBA/readparams.cpp:444-519 readInitialSBAEstimate (restated as psba_read_problem)
+ *
+ * Conventions are the reference's: cnp = 6 (local-quaternion vector part 3 + translation 3),
+ * pnp = 3, mnp = 2 (CL_files/PSBA.cl:5-7); all arithmetic fp64; K[5] = (fu,u0,v0,ar,s) per
+ * camera, held fixed; initrot = unit quaternion, scalar first; observations sorted
+ * point-major, camera ascending inside a point (PSBA/misc.cpp:189-216).
+ *
+ * Plain pointers and sizes only.  Host arrays are owned by the caller; everything on the
+ * device is owned by the opaque handle.  One handle = one GPU = one host thread.  Calls
+ * are asynchronous on the handle's stream and synchronise only where a value is returned
+ * to the host.  No call exits the process: every entry point returns an int status
+ * (0 ok, > 0 numerical, < 0 API / usage error) and psba_last_error() gives the text.
+ */
+#ifndef PSBA_HIP_H
+#define PSBA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psba_ctx *psba_handle;
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define PSBA_OK 0
+#define PSBA_NOT_SPD 1     /* Cholesky met a non-positive / non-finite pivot (SPDinv ret==1.0,
+                              PSBA/cl_spdinv.cpp:85-102, CL_files/SPD_inv.cl:35-38,66) */
+#define PSBA_SINGULAR_V 2  /* some |det V_i| < 1e-16 (compute_Vinv ret==1.0,
+                              CL_files/compute_Vinv.cl:31-32) */
+#define PSBA_E_INVALID (-1)
+#define PSBA_E_HIP (-2)
+#define PSBA_E_RCCL (-3)
+#define PSBA_E_IO (-4)
+#define PSBA_E_NOMEM (-5)
+#define PSBA_E_STATE (-6)  /* verb called before the state it needs exists */
+
+/* iteration flags of the optimiser loops, PSBA/psba.h:12-18 (same numbering) */
+#define PSBA_ITER_TURN_TO_LM 1
+#define PSBA_ITER_TURN_TO_TR 2
+#define PSBA_ITER_CONTINUE 3
+#define PSBA_ITER_ERR 4
+#define PSBA_ITER_DP_NO_CHANGE 5
+#define PSBA_ITER_ERR_SMALL_ENOUGH 6
+#define PSBA_ITER_PASS 7
+
+/* which parameter set a verb evaluates: cams_buffer/pts3D_buffer or
+ * newCams_buffer/newPts3D_buffer (PSBA/sba_func.h:15-16, PSBA/levmar.cpp:93,188-189) */
+#define PSBA_PARAMS_CUR 0
+#define PSBA_PARAMS_NEW 1
+
+/* ---- lifecycle: setup_cl / release_buffer (PSBA/cl_psba.h:93-94) --------------------- */
+int psba_create(int device, psba_handle *out);
+int psba_destroy(psba_handle h);
+/* text of the last error on this handle (h may be NULL: last error of a failed create) */
+const char *psba_last_error(psba_handle h);
+/* version string of the library and the code-object architecture it was built for */
+const char *psba_version(void);
+
+/* ---- problem upload: fill_initBuffer2 + generate_idxs + fill_idxBuffer ----------------
+ * (PSBA/cl_psba.h:114-126, PSBA/misc.cpp:178-217, call order PSBA/main.cpp:177-189).
+ * Kparas[nCams*5], impts[n2Dprojs*2], initrot[nCams*4], camsEx[nCams*6], pts3D[n3Dpts*3],
+ * iidx/jidx[n2Dprojs] (point / camera of each observation, point-major sorted).
+ * The dense blk_idx / comm3DIdx tables of the reference are not needed: a point CSR and
+ * point-aligned observation tiles are built inside. */
+int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, const double *Kparas,
+                        const double *impts, const double *initrot, const double *camsEx,
+                        const double *pts3D, const int *iidx, const int *jidx);
+/* overwrite the current parameters (cams[nCams*6], pts[n3Dpts*3]) */
+int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D);
+/* read back the current (PSBA_PARAMS_CUR) or proposed (PSBA_PARAMS_NEW) parameters */
+int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
+int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
+
+/* ---- fused verbs (what the optimiser loops call) --------------------------------------
+ * One damping try = psba_schur_assemble -> psba_schur_reduce -> psba_schur_solve ->
+ * psba_backsub; nothing is copied to the host in between. */
+
+/* ||e||^2 at a parameter set: compute_exQT + compute_L2_sq
+ * (PSBA/sba_func.h:10-19, PSBA/levmar.cpp:93-94,188-193, PSBA/misc.cpp:151-157).
+ * With a communicator attached the value is summed over all ranks. */
+int psba_residual(psba_handle h, int which, double *cost);
+/* compute_jacobiQT + compute_U + compute_V + compute_Wblks + compute_g in one kernel
+ * (PSBA/sba_func.h:26-56,74-81,103-109; PSBA/levmar.cpp:103-108).  coeff scales U,V,W
+ * (1 in LM, 2 in TR), coeff_g scales g (1 in LM, -2 in TR; PSBA/trust_region.cpp:122,133-137).
+ * A/B/e are never written to memory. */
+int psba_linearize(psba_handle h, double coeff, double coeff_g);
+/* maxElmOfUV (PSBA/sba_func.h:58): max over diag(U), diag(V); global over ranks */
+int psba_max_diag(psba_handle h, double *out);
+/* update_UV + compute_Vinv + compute_Yblks + compute_S + compute_ea
+ * (PSBA/sba_func.h:60-68,84-98,114-119; PSBA/levmar.cpp:126-131).  mu is applied on the
+ * fly, U/V are not modified, so there is no restore_UVdiag.  Leaves this rank's
+ * contribution to [S | ea] in the reduce buffer. */
+int psba_schur_assemble(psba_handle h, double mu);
+/* sum [S | ea] over ranks with one RCCL all-reduce on the handle's stream; no-op without a
+ * communicator.  (No counterpart in the reference: it is single-device.) */
+int psba_schur_reduce(psba_handle h);
+/* SPDinv + matVec_mul as one Cholesky factorisation and two triangular solves
+ * (PSBA/cl_spdinv.h:7-8, PSBA/cl_linearalg.h:8-9, PSBA/levmar.cpp:134-140).  The status
+ * (PSBA_OK / PSBA_NOT_SPD) stays on the device until psba_backsub returns it. */
+int psba_schur_solve(psba_handle h);
+
+typedef struct {
+  int status;       /* PSBA_OK, PSBA_NOT_SPD, PSBA_SINGULAR_V (bit-or) */
+  double dp_l2;     /* ||dp||^2                         PSBA/levmar.cpp:157 */
+  double gain_den;  /* sum dp*(mu*dp+g)                 PSBA/levmar.cpp:271-280 */
+  double new_cost;  /* ||e(p+dp)||^2                    PSBA/levmar.cpp:188-193 */
+  double newp_l2;   /* ||p+dp||^2                       PSBA/levmar.cpp:212 */
+} psba_try_scalars;
+
+/* compute_eb + compute_dpb + compute_newp + compute_exQT(new) + the host reductions the
+ * loop needs, in one kernel (PSBA/sba_func.h:124-137, PSBA/levmar.cpp:151-195).
+ * Synchronises and fills *out (all-reduced over ranks). */
+int psba_backsub(psba_handle h, double mu, psba_try_scalars *out);
+/* update_p (PSBA/sba_func.h:138): the proposed parameters become current (pointer swap) */
+int psba_accept(psba_handle h);
+
+/* ---- 1:1 mirror of sba_func.h for per-kernel parity tests -----------------------------
+ * Same names and argument meaning as the reference; the dimension arguments and
+ * PSBA_structPtr collapse into the handle.  A NULL host pointer means "stay on device"
+ * exactly as in the reference.  Each verb leaves the device state as the reference's
+ * wrapper of the same name does. */
+int psba_compute_exQT(psba_handle h, int which, double *ex);             /* sba_func.h:10-19 */
+int psba_compute_jacobiQT(psba_handle h, double *jac_A, double *jac_B);  /* sba_func.h:26-32 */
+int psba_compute_U(psba_handle h, double coeff, double *out);            /* sba_func.h:38-44 */
+int psba_compute_V(psba_handle h, double coeff, double *out);            /* sba_func.h:50-56 */
+int psba_maxElmOfUV(psba_handle h, double *out);                         /* sba_func.h:58 */
+int psba_update_UV(psba_handle h, double mu, double *U, double *V);      /* sba_func.h:60-61 */
+int psba_restore_UVdiag(psba_handle h);                                  /* sba_func.cpp:694 */
+int psba_compute_Vinv(psba_handle h, double *Vinv /* n3Dpts*9, full symmetric */); /* :63-68 */
+int psba_compute_Wblks(psba_handle h, double coeff, double *Wblks);      /* sba_func.h:74-81 */
+int psba_compute_Yblks(psba_handle h, double *Yblks);                    /* sba_func.h:84-90 */
+int psba_compute_S(psba_handle h, double *S /* (6 nCams)^2 row-major */); /* sba_func.h:93-98 */
+int psba_compute_g(psba_handle h, double coeff, double *g);              /* sba_func.h:103-109 */
+int psba_compute_ea(psba_handle h, double *ea);                          /* sba_func.h:114-119 */
+/* SPDinv + matVec_mul: returns PSBA_OK / PSBA_NOT_SPD like SPDinv's 0.0 / 1.0; dpa[6 nCams] */
+int psba_SPDinv_matVec(psba_handle h, double *dpa);          /* cl_spdinv.h:7, cl_linearalg.h:8 */
+int psba_compute_eb(psba_handle h, double *eb /* 3 n3Dpts */);           /* sba_func.h:124-129 */
+int psba_compute_dpb(psba_handle h, double *dp /* whole dp, nT */);      /* sba_func.h:131-135 */
+int psba_compute_newp(psba_handle h, double *new_p /* nT */);            /* sba_func.h:137 */
+int psba_update_p(psba_handle h, double *p /* nT */);                    /* sba_func.h:138 */
+
+/* ---- the Levenberg-Marquardt caller, PSBA/levmar.cpp:45-256 --------------------------- */
+typedef struct {
+  int max_iter;     /* literal 50 in the reference (levmar.cpp:100) */
+  int tr_handoff;   /* 1: return PSBA_ITER_TURN_TO_TR after 5 consecutive |rho-1|<0.2
+                       (levmar.cpp:215-219); 0: stay in LM */
+  int verbose;      /* print the reference's per-try line (levmar.cpp:197) */
+  int log_cap;      /* rows available in log (5 doubles each), 0 = none */
+  int start_itno;   /* the reference shares itno between LM and TR (main.cpp:193-208) */
+} psba_lm_options;
+
+typedef struct {
+  int flag;         /* PSBA_ITER_* */
+  int iters;        /* value of itno at exit */
+  int tries;        /* damping tries executed */
+  double init_err, final_err, mu0, mu_final;
+  int n_log;
+  double seconds;   /* wall time inside the loop */
+} psba_lm_result;
+
+void psba_lm_default_options(psba_lm_options *o);
+/* log rows: (itno, new ||e||^2, rho, mu, accepted{1,0,-1=solve failed}) per damping try */
+int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res, double *log);
+
+/* ---- multi-GPU: 3-D points sharded over ranks, one process per GPU -------------------- */
+/* contiguous point ranges balanced on observation count; pt_begin[nranks+1] */
+int psba_partition_points(int n3Dpts, const int *iidx, int n2Dprojs, int nranks, int *pt_begin);
+/* 128-byte RCCL unique id, created on rank 0 and handed to every rank by the launcher */
+int psba_comm_unique_id(void *id128);
+int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128);
+int psba_comm_rank(psba_handle h, int *nranks, int *rank);
+
+/* ---- on-disk format: readInitialSBAEstimate (PSBA/readparams.cpp:444-519) -------------
+ * Reads an sba-format cams file (7 columns q,t with fixedK[5] replicated, or 12 columns
+ * K5,q,t) and pts file; applies quat2vec (PSBA/misc.cpp:21-49), zeroes the local rotation
+ * and splits K from the extrinsics (PSBA/main.cpp:131-149).  Arrays are malloc'ed by the
+ * library and released with psba_free_problem. */
+typedef struct {
+  int nCams, n3Dpts, n2Dprojs;
+  double *Kparas, *impts, *initrot, *camsEx, *pts3D;
+  int *iidx, *jidx;
+} psba_problem;
+int psba_read_problem(const char *cams_file, const char *pts_file, const double *fixedK,
+                      psba_problem *out);
+void psba_free_problem(psba_problem *p);
+
+/* ---- measurement ----------------------------------------------------------------------
+ * HIP-event timing of the kernels launched by the fused verbs, on the handle's stream. */
+#define PSBA_K_LINEARIZE 0
+#define PSBA_K_SCHUR 1
+#define PSBA_K_CHOLESKY 2
+#define PSBA_K_BACKSUB 3
+#define PSBA_K_RESIDUAL 4
+#define PSBA_K_ALLREDUCE 5
+#define PSBA_K_COUNT 6
+int psba_profile_enable(psba_handle h, int on);
+int psba_profile_reset(psba_handle h);
+/* total_ms and launch count per kernel class since the last reset (synchronises) */
+int psba_profile_get(psba_handle h, int kernel, double *total_ms, int *launches);
+/* algorithmic bytes of one launch of a kernel class for the uploaded problem
+ * (SURVEY.md section 8(d) formulas; stated in DESIGN.md) */
+int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

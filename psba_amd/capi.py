@@ -1,0 +1,344 @@
+"""ctypes binding of include/psba_hip.h (one method per entry point, same names)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libpsba_hip.so")
+
+if not os.path.exists(lib_path):
+    raise ImportError(
+        f"{lib_path} is missing: build the HIP extension first (python -m psba_amd.build, or "
+        "__graft_entry__.build()). psba_amd has no CPU fallback.")
+lib = C.CDLL(lib_path)
+
+PSBA_OK, PSBA_NOT_SPD, PSBA_SINGULAR_V = 0, 1, 2
+PARAMS_CUR, PARAMS_NEW = 0, 1
+ITER_TURN_TO_LM, ITER_TURN_TO_TR, ITER_CONTINUE, ITER_ERR = 1, 2, 3, 4
+ITER_DP_NO_CHANGE, ITER_ERR_SMALL_ENOUGH, ITER_PASS = 5, 6, 7
+K_LINEARIZE, K_SCHUR, K_CHOLESKY, K_BACKSUB, K_RESIDUAL, K_ALLREDUCE = range(6)
+KERNEL_NAMES = ["linearize", "schur", "cholesky", "backsub", "residual", "allreduce"]
+
+_h = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class TryScalars(C.Structure):
+    _fields_ = [("status", C.c_int), ("dp_l2", C.c_double), ("gain_den", C.c_double),
+                ("new_cost", C.c_double), ("newp_l2", C.c_double)]
+
+
+class LmOptions(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("tr_handoff", C.c_int), ("verbose", C.c_int),
+                ("log_cap", C.c_int), ("start_itno", C.c_int)]
+
+
+class LmResult(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iters", C.c_int), ("tries", C.c_int), ("init_err", C.c_double),
+                ("final_err", C.c_double), ("mu0", C.c_double), ("mu_final", C.c_double),
+                ("n_log", C.c_int), ("seconds", C.c_double)]
+
+
+class CProblem(C.Structure):
+    _fields_ = [("nCams", C.c_int), ("n3Dpts", C.c_int), ("n2Dprojs", C.c_int), ("Kparas", _dp),
+                ("impts", _dp), ("initrot", _dp), ("camsEx", _dp), ("pts3D", _dp), ("iidx", _ip),
+                ("jidx", _ip)]
+
+
+# every symbol include/psba_hip.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("psba_create", C.c_int, [C.c_int, C.POINTER(_h)]),
+    ("psba_destroy", C.c_int, [_h]),
+    ("psba_last_error", C.c_char_p, [_h]),
+    ("psba_version", C.c_char_p, []),
+    ("psba_upload_problem", C.c_int, [_h, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
+    ("psba_set_params", C.c_int, [_h, _dp, _dp]),
+    ("psba_get_params", C.c_int, [_h, C.c_int, _dp, _dp]),
+    ("psba_get_dims", C.c_int, [_h, _ip, _ip, _ip]),
+    ("psba_residual", C.c_int, [_h, C.c_int, _dp]),
+    ("psba_linearize", C.c_int, [_h, C.c_double, C.c_double]),
+    ("psba_max_diag", C.c_int, [_h, _dp]),
+    ("psba_schur_assemble", C.c_int, [_h, C.c_double]),
+    ("psba_schur_reduce", C.c_int, [_h]),
+    ("psba_schur_solve", C.c_int, [_h]),
+    ("psba_backsub", C.c_int, [_h, C.c_double, C.POINTER(TryScalars)]),
+    ("psba_accept", C.c_int, [_h]),
+    ("psba_compute_exQT", C.c_int, [_h, C.c_int, _dp]),
+    ("psba_compute_jacobiQT", C.c_int, [_h, _dp, _dp]),
+    ("psba_compute_U", C.c_int, [_h, C.c_double, _dp]),
+    ("psba_compute_V", C.c_int, [_h, C.c_double, _dp]),
+    ("psba_maxElmOfUV", C.c_int, [_h, _dp]),
+    ("psba_update_UV", C.c_int, [_h, C.c_double, _dp, _dp]),
+    ("psba_restore_UVdiag", C.c_int, [_h]),
+    ("psba_compute_Vinv", C.c_int, [_h, _dp]),
+    ("psba_compute_Wblks", C.c_int, [_h, C.c_double, _dp]),
+    ("psba_compute_Yblks", C.c_int, [_h, _dp]),
+    ("psba_compute_S", C.c_int, [_h, _dp]),
+    ("psba_compute_g", C.c_int, [_h, C.c_double, _dp]),
+    ("psba_compute_ea", C.c_int, [_h, _dp]),
+    ("psba_SPDinv_matVec", C.c_int, [_h, _dp]),
+    ("psba_compute_eb", C.c_int, [_h, _dp]),
+    ("psba_compute_dpb", C.c_int, [_h, _dp]),
+    ("psba_compute_newp", C.c_int, [_h, _dp]),
+    ("psba_update_p", C.c_int, [_h, _dp]),
+    ("psba_lm_default_options", None, [C.POINTER(LmOptions)]),
+    ("psba_levmar", C.c_int, [_h, C.POINTER(LmOptions), C.POINTER(LmResult), _dp]),
+    ("psba_partition_points", C.c_int, [C.c_int, _ip, C.c_int, C.c_int, _ip]),
+    ("psba_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("psba_comm_init", C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    ("psba_comm_rank", C.c_int, [_h, _ip, _ip]),
+    ("psba_read_problem", C.c_int, [C.c_char_p, C.c_char_p, _dp, C.POINTER(CProblem)]),
+    ("psba_free_problem", None, [C.POINTER(CProblem)]),
+    ("psba_profile_enable", C.c_int, [_h, C.c_int]),
+    ("psba_profile_reset", C.c_int, [_h]),
+    ("psba_profile_get", C.c_int, [_h, C.c_int, _dp, _ip]),
+    ("psba_algorithmic_bytes", C.c_int, [_h, C.c_int, _dp]),
+]
+for _name, _res, _args in SIGNATURES:
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class PsbaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"psba error {code}: {msg}")
+        self.code = code
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Problem(dict):
+    """K[nC,5] initrot[nC,4] cams[nC,6] pts[nP,3] impts[nO,2] iidx[nO] jidx[nO] nC nP nO."""
+
+
+def read_problem(cams_file, pts_file, fixedK=None):
+    """psba_read_problem -> Problem (host only, works without a GPU)."""
+    cp = CProblem()
+    k = None if fixedK is None else _c(fixedK)
+    rc = lib.psba_read_problem(os.fsencode(cams_file), os.fsencode(pts_file), _d(k), C.byref(cp))
+    if rc != 0:
+        raise PsbaError(rc, f"psba_read_problem({cams_file}, {pts_file}) failed")
+    nC, nP, nO = cp.nCams, cp.n3Dpts, cp.n2Dprojs
+    arr = lambda p, n, shape: np.ctypeslib.as_array(p, shape=(n,)).copy().reshape(shape)
+    out = Problem(K=arr(cp.Kparas, 5 * nC, (nC, 5)), initrot=arr(cp.initrot, 4 * nC, (nC, 4)),
+                  cams=arr(cp.camsEx, 6 * nC, (nC, 6)), pts=arr(cp.pts3D, 3 * nP, (nP, 3)),
+                  impts=arr(cp.impts, 2 * nO, (nO, 2)), iidx=arr(cp.iidx, nO, (nO,)).astype(np.int32),
+                  jidx=arr(cp.jidx, nO, (nO,)).astype(np.int32), nC=nC, nP=nP, nO=nO)
+    lib.psba_free_problem(C.byref(cp))
+    return out
+
+
+def partition_points(n_pts, iidx, nranks):
+    iidx = _c(iidx, np.int32)
+    out = np.zeros(nranks + 1, dtype=np.int32)
+    rc = lib.psba_partition_points(int(n_pts), _i(iidx), int(iidx.size), int(nranks), _i(out))
+    if rc != 0:
+        raise PsbaError(rc, "psba_partition_points failed")
+    return out
+
+
+def shard_problem(prob, nranks, rank):
+    """The sub-problem rank `rank` owns: a contiguous point range and its observations;
+    cameras are replicated."""
+    bounds = partition_points(prob["nP"], prob["iidx"], nranks)
+    p0, p1 = int(bounds[rank]), int(bounds[rank + 1])
+    iidx = np.asarray(prob["iidx"])
+    sel = (iidx >= p0) & (iidx < p1)
+    return Problem(K=prob["K"], initrot=prob["initrot"], cams=prob["cams"], pts=prob["pts"][p0:p1],
+                   impts=np.asarray(prob["impts"])[sel], iidx=(iidx[sel] - p0).astype(np.int32),
+                   jidx=np.asarray(prob["jidx"])[sel].astype(np.int32), nC=prob["nC"], nP=p1 - p0,
+                   nO=int(sel.sum()))
+
+
+class Psba:
+    """One handle = one GPU.  Methods are the C entry points without the psba_ prefix."""
+
+    def __init__(self, device=0):
+        self._h = _h()
+        rc = lib.psba_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise PsbaError(rc, lib.psba_last_error(None).decode())
+        self.nC = self.nP = self.nO = 0
+
+    def close(self):
+        if self._h:
+            lib.psba_destroy(self._h)
+            self._h = _h()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise PsbaError(rc, lib.psba_last_error(self._h).decode())
+        return rc
+
+    # ---- setup ----
+    def upload_problem(self, prob):
+        self.nC, self.nP, self.nO = int(prob["nC"]), int(prob["nP"]), int(prob["nO"])
+        self.nA, self.nB = 6 * self.nC, 3 * self.nP
+        self.nT = self.nA + self.nB
+        a = [_c(prob[k]).reshape(-1) for k in ("K", "impts", "initrot", "cams", "pts")]
+        ii, jj = _c(prob["iidx"], np.int32), _c(prob["jidx"], np.int32)
+        self._ck(lib.psba_upload_problem(self._h, self.nC, self.nP, self.nO, _d(a[0]), _d(a[1]),
+                                         _d(a[2]), _d(a[3]), _d(a[4]), _i(ii), _i(jj)))
+
+    def set_params(self, cams, pts):
+        c, p = _c(cams).reshape(-1), _c(pts).reshape(-1)
+        self._ck(lib.psba_set_params(self._h, _d(c), _d(p)))
+
+    def get_params(self, which=PARAMS_CUR):
+        c, p = np.empty(self.nA), np.empty(self.nB)
+        self._ck(lib.psba_get_params(self._h, which, _d(c), _d(p)))
+        return c.reshape(self.nC, 6), p.reshape(self.nP, 3)
+
+    # ---- fused verbs ----
+    def residual(self, which=PARAMS_CUR):
+        v = C.c_double()
+        self._ck(lib.psba_residual(self._h, which, C.byref(v)))
+        return v.value
+
+    def linearize(self, coeff=1.0, coeff_g=1.0):
+        self._ck(lib.psba_linearize(self._h, coeff, coeff_g))
+
+    def max_diag(self):
+        v = C.c_double()
+        self._ck(lib.psba_max_diag(self._h, C.byref(v)))
+        return v.value
+
+    def schur_assemble(self, mu):
+        self._ck(lib.psba_schur_assemble(self._h, mu))
+
+    def schur_reduce(self):
+        self._ck(lib.psba_schur_reduce(self._h))
+
+    def schur_solve(self):
+        self._ck(lib.psba_schur_solve(self._h))
+
+    def backsub(self, mu):
+        s = TryScalars()
+        self._ck(lib.psba_backsub(self._h, mu, C.byref(s)))
+        return s
+
+    def accept(self):
+        self._ck(lib.psba_accept(self._h))
+
+    # ---- sba_func.h mirror ----
+    def _out(self, fn, n, *pre):
+        out = np.empty(n)
+        rc = self._ck(fn(self._h, *pre, _d(out)))
+        return rc, out
+
+    def compute_exQT(self, which=PARAMS_CUR):
+        return self._out(lib.psba_compute_exQT, 2 * self.nO, which)[1]
+
+    def compute_jacobiQT(self):
+        JA, JB = np.empty(12 * self.nO), np.empty(6 * self.nO)
+        self._ck(lib.psba_compute_jacobiQT(self._h, _d(JA), _d(JB)))
+        return JA, JB
+
+    def compute_U(self, coeff=1.0):
+        return self._out(lib.psba_compute_U, 36 * self.nC, coeff)[1]
+
+    def compute_V(self, coeff=1.0):
+        return self._out(lib.psba_compute_V, 9 * self.nP, coeff)[1]
+
+    def maxElmOfUV(self):
+        v = C.c_double()
+        self._ck(lib.psba_maxElmOfUV(self._h, C.byref(v)))
+        return v.value
+
+    def update_UV(self, mu):
+        U, V = np.empty(36 * self.nC), np.empty(9 * self.nP)
+        self._ck(lib.psba_update_UV(self._h, mu, _d(U), _d(V)))
+        return U, V
+
+    def restore_UVdiag(self):
+        self._ck(lib.psba_restore_UVdiag(self._h))
+
+    def compute_Vinv(self):
+        return self._out(lib.psba_compute_Vinv, 9 * self.nP)
+
+    def compute_Wblks(self, coeff=1.0):
+        return self._out(lib.psba_compute_Wblks, 18 * self.nO, coeff)[1]
+
+    def compute_Yblks(self):
+        return self._out(lib.psba_compute_Yblks, 18 * self.nO)[1]
+
+    def compute_S(self):
+        return self._out(lib.psba_compute_S, self.nA * self.nA)[1].reshape(self.nA, self.nA)
+
+    def compute_g(self, coeff=1.0):
+        return self._out(lib.psba_compute_g, self.nT, coeff)[1]
+
+    def compute_ea(self):
+        return self._out(lib.psba_compute_ea, self.nA)[1]
+
+    def SPDinv_matVec(self):
+        return self._out(lib.psba_SPDinv_matVec, self.nA)
+
+    def compute_eb(self):
+        return self._out(lib.psba_compute_eb, self.nB)[1]
+
+    def compute_dpb(self):
+        return self._out(lib.psba_compute_dpb, self.nT)[1]
+
+    def compute_newp(self):
+        return self._out(lib.psba_compute_newp, self.nT)[1]
+
+    def update_p(self):
+        return self._out(lib.psba_update_p, self.nT)[1]
+
+    # ---- LM ----
+    def levmar(self, max_iter=50, tr_handoff=False, verbose=False, log_cap=512, start_itno=0):
+        opts = LmOptions(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno)
+        res = LmResult()
+        log = np.zeros((max(log_cap, 1), 5))
+        self._ck(lib.psba_levmar(self._h, C.byref(opts), C.byref(res), _d(log)))
+        return res, log[: res.n_log].copy()
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib.psba_comm_unique_id(buf)
+        if rc != 0:
+            raise PsbaError(rc, "psba_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid):
+        buf = C.create_string_buffer(uid, 128)
+        self._ck(lib.psba_comm_init(self._h, nranks, rank, buf))
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._ck(lib.psba_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(lib.psba_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int()
+        self._ck(lib.psba_profile_get(self._h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def algorithmic_bytes(self, kernel):
+        b = C.c_double()
+        self._ck(lib.psba_algorithmic_bytes(self._h, kernel, C.byref(b)))
+        return b.value

@@ -1,0 +1,188 @@
+// kernels_backsub.hip -- K3: point back-substitution, proposal and its cost in one pass.
+//
+// Replaces kern_compute_eb, kern_compute_dpb, kern_compute_newp, the second
+// kern_compute_exQT of a damping try and the host-side compute_L2_sq / compute_rho sums
+// (reference CL_files/compute_eb.cl:6-41, compute_dpb.cl:6-35, compute_newp.cl:6-26,
+// compute_exQT.cl:18-71; PSBA/sba_func.cpp:1001-1213; PSBA/levmar.cpp:151-195,271-280;
+// PSBA/misc.cpp:151-157).  The reference copies dp (nT doubles) and ex (2 nO doubles) to the
+// host on every try; here only four scalars leave the device.
+//
+// Per tile of whole points: thread per observation forms W_ij^T dpa_j; thread per point
+// finishes e_b,i, applies V*_i^-1, writes dpb_i and the proposed point; thread per
+// observation then evaluates the residual at the proposal.
+#include "camera_model.h"
+#include "psba_internal.h"
+
+namespace psba {
+
+struct BackArgs {
+  const double *W, *PV, *camconst, *cams, *pts, *impts, *ga;
+  const int *iidx, *jidx, *ptr, *tile_pt;
+  double *dp;          // [nA] dpa (in) | [nB] dpb (out)
+  double *newcams, *newpts;
+  double *scal;        // SC_DP_L2, SC_GAIN_DEN, SC_NEW_COST, SC_NEWP_L2 accumulate here
+  double *dbg_eb;
+  double mu;
+  int nC, nA, nTiles;
+  int cam_terms;       // 1 on the rank that owns the camera terms of the scalar sums
+};
+
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
+  __shared__ double sT[TILE_OBS][3];   // W_a^T dpa_j per observation
+  __shared__ double sNP[TILE_OBS][3];  // proposed point per point of the tile
+  __shared__ double sRed[4][4];
+  const int tid = threadIdx.x;
+  double s_dp = 0.0, s_den = 0.0, s_cost = 0.0, s_np = 0.0;
+
+  // camera part (once): proposal cams + dpa and the camera terms of the scalar sums.
+  // g_a here is this rank's partial; the sum over ranks of dpa.g_a is the full term.
+  if (blockIdx.x == 0) {
+    for (int t = tid; t < p.nA; t += TILE_OBS) {
+      const double d = p.dp[t], c = p.cams[t] + d;
+      p.newcams[t] = c;
+      s_den += d * p.ga[t];
+      if (p.cam_terms) {
+        s_dp += d * d;
+        s_den += p.mu * d * d;
+        s_np += c * c;
+      }
+    }
+  }
+
+  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
+    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
+    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+    const int a = o0 + tid;
+    int i = 0, j = 0;
+    __syncthreads();
+    if (a < o1) {
+      i = p.iidx[a];
+      j = p.jidx[a];
+      const double *w = p.W + 18 * (size_t)a;
+      const double *da = p.dp + 6 * j;
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double dk = da[k];
+        t0 += w[3 * k] * dk;
+        t1 += w[3 * k + 1] * dk;
+        t2 += w[3 * k + 2] * dk;
+      }
+      sT[tid][0] = t0;
+      sT[tid][1] = t1;
+      sT[tid][2] = t2;
+    }
+    __syncthreads();
+    if (p0 + tid < p1) {
+      const int ip = p0 + tid;
+      const double *pv = p.PV + 9 * (size_t)ip;
+      const int b0 = p.ptr[ip] - o0, b1 = p.ptr[ip + 1] - o0;
+      const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+      for (int b = b0; b < b1; b++) {
+        e0 += sT[b][0];
+        e1 += sT[b][1];
+        e2 += sT[b][2];
+      }
+      e0 = g0 - e0;
+      e1 = g1 - e1;
+      e2 = g2 - e2;
+      if (DUMP) {
+        p.dbg_eb[3 * (size_t)ip] = e0;
+        p.dbg_eb[3 * (size_t)ip + 1] = e1;
+        p.dbg_eb[3 * (size_t)ip + 2] = e2;
+      }
+      double v[6], vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = pv[k];
+      v[0] += p.mu;
+      v[3] += p.mu;
+      v[5] += p.mu;
+      sym3_inverse(v, vi);
+      const double d0 = vi[0] * e0 + vi[1] * e1 + vi[2] * e2;
+      const double d1 = vi[1] * e0 + vi[3] * e1 + vi[4] * e2;
+      const double d2 = vi[2] * e0 + vi[4] * e1 + vi[5] * e2;
+      double *dpb = p.dp + p.nA + 3 * (size_t)ip;
+      dpb[0] = d0;
+      dpb[1] = d1;
+      dpb[2] = d2;
+      const double *M = p.pts + 3 * (size_t)ip;
+      const double n0 = M[0] + d0, n1 = M[1] + d1, n2 = M[2] + d2;
+      double *np = p.newpts + 3 * (size_t)ip;
+      np[0] = n0;
+      np[1] = n1;
+      np[2] = n2;
+      sNP[tid][0] = n0;
+      sNP[tid][1] = n1;
+      sNP[tid][2] = n2;
+      s_dp += d0 * d0 + d1 * d1 + d2 * d2;
+      s_den += d0 * (p.mu * d0 + g0) + d1 * (p.mu * d1 + g1) + d2 * (p.mu * d2 + g2);
+      s_np += n0 * n0 + n1 * n1 + n2 * n2;
+    }
+    __syncthreads();
+    if (a < o1) {
+      double cc[9], cam[6], e0, e1;
+#pragma unroll
+      for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k] + p.dp[6 * j + k];
+      const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
+      residual_obs(cc, cc + 5, cam, sNP[i - p0], m.x, m.y, e0, e1);
+      s_cost += e0 * e0 + e1 * e1;
+    }
+  }
+  // workgroup reduction of the four sums, one atomic each
+  double v4[4] = {s_dp, s_den, s_cost, s_np};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double v = v4[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) sRed[q][tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const double v = sRed[tid][0] + sRed[tid][1] + sRed[tid][2] + sRed[tid][3];
+    atomicAdd(&p.scal[SC_DP_L2 + tid], v);
+  }
+}
+
+int launch_backsub(psba_ctx *h, double mu, bool dump) {
+  const Dims &d = h->d;
+  BackArgs a;
+  a.W = h->W;
+  a.PV = h->PV;
+  a.camconst = h->camconst;
+  a.cams = h->cams[h->cur];
+  a.pts = h->pts[h->cur];
+  a.impts = h->impts;
+  a.ga = h->ga;
+  a.iidx = h->iidx;
+  a.jidx = h->jidx;
+  a.ptr = h->ptr;
+  a.tile_pt = h->tile_pt;
+  a.dp = h->dp;
+  a.newcams = h->cams[1 - h->cur];
+  a.newpts = h->pts[1 - h->cur];
+  a.scal = h->scal;
+  a.dbg_eb = h->dbg_eb;
+  a.mu = mu;
+  a.nC = d.nC;
+  a.nA = d.nA;
+  a.nTiles = d.nTiles;
+  a.cam_terms = h->rank == 0 ? 1 : 0;
+  PSBA_HIP(h, hipMemsetAsync(h->scal + SC_DP_L2, 0, 4 * sizeof(double), h->stream));
+  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  {
+    ProfScope ps(h, PSBA_K_BACKSUB);
+    if (dump)
+      hipLaunchKernelGGL(k_backsub<true>, dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+  }
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+}  // namespace psba

@@ -1,0 +1,249 @@
+// kernels_linearize.hip -- K1: residual + Jacobian + U/V/W/g assembly in one pass (fp64).
+//
+// Replaces kern_compute_exQT, kern_compute_jacobiQT, kern_compute_U, kern_compute_V,
+// kern_compute_Wblks, kern_compute_g (reference CL_files/compute_exQT.cl:18-71,
+// compute_jacobiQT.cl:7-141, compute_U.cl:5-35, compute_V.cl:6-38, compute_Wblks.cl:7-34,
+// compute_g.cl:6-60) and their wrappers PSBA/sba_func.cpp:81-617.
+//
+// Layout: observations are point-major; a *tile* is a run of whole points with at most
+// TILE_OBS observations, one thread per observation.  A/B/e live in registers; B and e go
+// through LDS once so that one thread per point sums V_i and g_b,i in camera order (the
+// reference's summation order); the 27 per-camera sums (sym U_j, g_a,j) are accumulated in
+// LDS per workgroup and written once per workgroup as a partial slab that k_cam_reduce
+// sums in slab order.  Nothing per-observation except W is written to HBM.
+#include "camera_model.h"
+#include "psba_internal.h"
+
+namespace psba {
+
+struct LinArgs {
+  const double *camconst, *cams, *pts, *impts;
+  const int *iidx, *jidx, *ptr, *tile_pt;
+  double *W, *PV, *campart;
+  double *dbg_ex, *dbg_JA, *dbg_JB;
+  double coeff, coeff_g;
+  int nC, nTiles;
+};
+
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
+  __shared__ double sBE[TILE_OBS][8];  // B(6) | e(2) per observation of the tile
+  extern __shared__ double sAcc[];     // [nC][27]
+  const int tid = threadIdx.x;
+  const int nAcc = p.nC * CAM_ACC;
+  for (int t = tid; t < nAcc; t += TILE_OBS) sAcc[t] = 0.0;
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
+    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
+    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+    const int a = o0 + tid;
+    if (a < o1) {
+      const int i = p.iidx[a], j = p.jidx[a];
+      double cc[9], cam[6], M[3], e[2], A[12], B[6];
+#pragma unroll
+      for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) M[k] = p.pts[3 * i + k];
+      const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
+      linearize_obs(cc, cc + 5, cam, M, m.x, m.y, e, A, B);
+      if (DUMP) {
+        p.dbg_ex[2 * a] = e[0];
+        p.dbg_ex[2 * a + 1] = e[1];
+#pragma unroll
+        for (int k = 0; k < 12; k++) p.dbg_JA[12 * (size_t)a + k] = A[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.dbg_JB[6 * (size_t)a + k] = B[k];
+      }
+      // W_ij = coeff * A^T B, 6x3 row-major
+      double *w = p.W + 18 * (size_t)a;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) w[3 * r + c] = p.coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) sBE[tid][k] = B[k];
+      sBE[tid][6] = e[0];
+      sBE[tid][7] = e[1];
+      // camera sums: upper triangle of A^T A, then A^T e
+      double *acc = sAcc + CAM_ACC * j;
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) atomicAdd(&acc[k++], A[r] * A[c] + A[6 + r] * A[6 + c]);
+#pragma unroll
+      for (int r = 0; r < 6; r++) atomicAdd(&acc[21 + r], A[r] * e[0] + A[6 + r] * e[1]);
+    }
+    __syncthreads();
+    // one thread per point: V_i (sym6) and g_b,i in camera-ascending order
+    const int i = p0 + tid;
+    if (i < p1) {
+      const int b0 = p.ptr[i] - o0, b1 = p.ptr[i + 1] - o0;
+      double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+      for (int b = b0; b < b1; b++) {
+        const double *B = sBE[b];
+        const double e0 = B[6], e1 = B[7];
+        v[0] += B[0] * B[0] + B[3] * B[3];
+        v[1] += B[0] * B[1] + B[3] * B[4];
+        v[2] += B[0] * B[2] + B[3] * B[5];
+        v[3] += B[1] * B[1] + B[4] * B[4];
+        v[4] += B[1] * B[2] + B[4] * B[5];
+        v[5] += B[2] * B[2] + B[5] * B[5];
+        g[0] += B[0] * e0 + B[3] * e1;
+        g[1] += B[1] * e0 + B[4] * e1;
+        g[2] += B[2] * e0 + B[5] * e1;
+      }
+      double *o = p.PV + 9 * (size_t)i;
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[k] = p.coeff * v[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[6 + k] = p.coeff_g * g[k];
+    }
+    __syncthreads();
+  }
+  double *slab = p.campart + (size_t)blockIdx.x * nAcc;
+  for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
+}
+
+// one workgroup per camera: sums the partial slabs in slab order, expands sym U_j to the
+// full 6x6 and scales (U by coeff, g_a by coeff_g).
+__global__ __launch_bounds__(256) void k_cam_reduce(const double *campart, int nPart, int nC,
+                                                    double coeff, double coeff_g, double *U,
+                                                    double *ga) {
+  __shared__ double sPart[8][32];
+  const int j = blockIdx.x, e = threadIdx.x & 31, s = threadIdx.x >> 5;
+  double acc = 0.0;
+  if (e < CAM_ACC)
+    for (int q = s; q < nPart; q += 8) acc += campart[((size_t)q * nC + j) * CAM_ACC + e];
+  sPart[s][e] = acc;
+  __syncthreads();
+  if (s == 0 && e < CAM_ACC) {
+    double t = sPart[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; q++) t += sPart[q][e];
+    sPart[0][e] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int k = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);  // index in the packed upper triangle
+    U[36 * j + threadIdx.x] = coeff * sPart[0][k];
+  } else if (threadIdx.x < 42) {
+    ga[6 * j + threadIdx.x - 36] = coeff_g * sPart[0][21 + threadIdx.x - 36];
+  }
+}
+
+// ---- residual: kern_compute_exQT + the host compute_L2_sq (PSBA/misc.cpp:151-157) -------
+__global__ __launch_bounds__(256) void k_residual(const double *camconst, const double *cams,
+                                                  const double *pts, const double *impts,
+                                                  const int *iidx, const int *jidx, int nO,
+                                                  double *ex_out, double *cost) {
+  __shared__ double sRed[4];
+  double sum = 0.0;
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nO; a += gridDim.x * blockDim.x) {
+    const int i = iidx[a], j = jidx[a];
+    double cc[9], cam[6], M[3], e0, e1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = camconst[9 * j + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cam[k] = cams[6 * j + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) M[k] = pts[3 * i + k];
+    const double2 m = reinterpret_cast<const double2 *>(impts)[a];
+    residual_obs(cc, cc + 5, cam, M, m.x, m.y, e0, e1);
+    if (ex_out) {
+      ex_out[2 * a] = e0;
+      ex_out[2 * a + 1] = e1;
+    }
+    sum += e0 * e0 + e1 * e1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(cost, sRed[0] + sRed[1] + sRed[2] + sRed[3]);
+}
+
+// ---- maxElmOfUV (PSBA/sba_func.cpp:422-444) --------------------------------------------
+__global__ __launch_bounds__(1024) void k_max_diag(const double *U, const double *PV, int nC,
+                                                   int nP, double *out) {
+  __shared__ double sRed[16];
+  double m = -INFINITY;
+  for (int t = threadIdx.x; t < 6 * nC; t += 1024) m = fmax(m, U[36 * (t / 6) + 7 * (t % 6)]);
+  for (int t = threadIdx.x; t < 3 * nP; t += 1024) {
+    const int i = t / 3, r = t % 3;
+    m = fmax(m, PV[9 * (size_t)i + (r == 0 ? 0 : (r == 1 ? 3 : 5))]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; k++) m = fmax(m, sRed[k]);
+    *out = m;
+  }
+}
+
+int launch_linearize(psba_ctx *h, bool dump) {
+  const Dims &d = h->d;
+  LinArgs a;
+  a.camconst = h->camconst;
+  a.cams = h->cams[h->cur];
+  a.pts = h->pts[h->cur];
+  a.impts = h->impts;
+  a.iidx = h->iidx;
+  a.jidx = h->jidx;
+  a.ptr = h->ptr;
+  a.tile_pt = h->tile_pt;
+  a.W = h->W;
+  a.PV = h->PV;
+  a.campart = h->campart;
+  a.dbg_ex = h->dbg_ex;
+  a.dbg_JA = h->dbg_JA;
+  a.dbg_JB = h->dbg_JB;
+  a.coeff = h->coeff;
+  a.coeff_g = h->coeff_g;
+  a.nC = d.nC;
+  a.nTiles = d.nTiles;
+  const size_t lds = sizeof(double) * CAM_ACC * (size_t)d.nC;
+  {
+    ProfScope ps(h, PSBA_K_LINEARIZE);
+    if (dump)
+      hipLaunchKernelGGL(k_linearize<true>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_linearize<false>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+    hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(256), 0, h->stream, h->campart, h->nPart,
+                       d.nC, h->coeff, h->coeff_g, h->U, h->ga);
+  }
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+int launch_residual(psba_ctx *h, int which, double *ex_out_dev) {
+  const Dims &d = h->d;
+  const int set = which == PSBA_PARAMS_NEW ? 1 - h->cur : h->cur;
+  PSBA_HIP(h, hipMemsetAsync(h->scal + SC_COST, 0, sizeof(double), h->stream));
+  int grid = (d.nO + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  {
+    ProfScope ps(h, PSBA_K_RESIDUAL);
+    hipLaunchKernelGGL(k_residual, dim3(grid), dim3(256), 0, h->stream, h->camconst, h->cams[set],
+                       h->pts[set], h->impts, h->iidx, h->jidx, d.nO, ex_out_dev,
+                       h->scal + SC_COST);
+  }
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+int launch_max_diag(psba_ctx *h) {
+  hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, h->stream, h->U, h->PV, h->d.nC, h->d.nP,
+                     h->scal + SC_MAXDIAG);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+}  // namespace psba

@@ -1,0 +1,175 @@
+// kernels_schur.hip -- K2: damping + V^-1 + Y = W V^-1 + S = U* - Y W^T + e_a = g_a - Y g_b.
+//
+// Replaces kern_update_UV, kern_compute_Vinv, kern_compute_Yblks, kern_compute_S,
+// kern_compute_ea and kern_restore_UVdiag (reference CL_files/update_UV.cl:5-31,
+// compute_Vinv.cl:6-90, compute_Yblks.cl:6-39, compute_S.cl:6-78, compute_ea.cl:6-37,
+// restore_UVdiag.cl:2-25) and their wrappers PSBA/sba_func.cpp:624-995.
+//
+// mu is added in registers (U, V are never modified, so nothing is restored); V^-1 and Y
+// are never written to HBM.  Point-major: a tile of whole points is staged in LDS (its W
+// blocks, V^-1, g_b), each thread owns one observation a, forms Y_a in registers and emits
+// the products Y_a W_b^T for every observation b <= a of the same point, i.e. the lower
+// block triangle of S (cameras ascend inside a point).  k_schur_finalize adds U + mu I and
+// g_a and mirrors the upper block triangle.
+#include "camera_model.h"
+#include "psba_internal.h"
+
+namespace psba {
+
+struct SchurArgs {
+  const double *W, *PV;
+  const int *iidx, *jidx, *ptr, *tile_pt;
+  double *S, *ea;          // accumulators (zeroed before launch): -sum Y W^T, -sum Y g_b
+  int *status;
+  double *dbg_Y, *dbg_Vinv;
+  double mu;
+  int nC, nA, nTiles;
+};
+
+// v1: global fp64 atomics straight into S (lower block triangle).
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
+  __shared__ double sW[TILE_OBS * 18];
+  __shared__ double sVi[TILE_OBS][9];  // V^-1 sym6 | g_b
+  __shared__ int sJ[TILE_OBS];
+  extern __shared__ double sEa[];      // [nA]
+  const int tid = threadIdx.x;
+  for (int t = tid; t < p.nA; t += TILE_OBS) sEa[t] = 0.0;
+
+  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
+    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
+    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+    const int nobs = o1 - o0;
+    __syncthreads();
+    // coalesced copy of the tile's W blocks
+    {
+      const double2 *src = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)o0);
+      double2 *dst = reinterpret_cast<double2 *>(sW);
+      for (int t = tid; t < nobs * 9; t += TILE_OBS) dst[t] = src[t];
+    }
+    if (tid < nobs) sJ[tid] = p.jidx[o0 + tid];
+    if (p0 + tid < p1) {
+      const double *pv = p.PV + 9 * (size_t)(p0 + tid);
+      double v[6], vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = pv[k];
+      v[0] += p.mu;
+      v[3] += p.mu;
+      v[5] += p.mu;
+      if (sym3_inverse(v, vi)) atomicOr(&p.status[0], 1);
+#pragma unroll
+      for (int k = 0; k < 6; k++) sVi[tid][k] = vi[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) sVi[tid][6 + k] = pv[6 + k];
+      if (DUMP) {
+        double *o = p.dbg_Vinv + 9 * (size_t)(p0 + tid);
+        o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
+        o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
+        o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
+      }
+    }
+    __syncthreads();
+    if (tid < nobs) {
+      const int a = o0 + tid;
+      const int i = p.iidx[a];
+      const int ja = sJ[tid];
+      const double *vi = sVi[i - p0];
+      const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+      const double g0 = vi[6], g1 = vi[7], g2 = vi[8];
+      double Y[18];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double w0 = sW[18 * tid + 3 * r], w1 = sW[18 * tid + 3 * r + 1],
+                     w2 = sW[18 * tid + 3 * r + 2];
+        Y[3 * r] = w0 * i00 + w1 * i01 + w2 * i02;
+        Y[3 * r + 1] = w0 * i01 + w1 * i11 + w2 * i12;
+        Y[3 * r + 2] = w0 * i02 + w1 * i12 + w2 * i22;
+        atomicAdd(&sEa[6 * ja + r], -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
+      }
+      if (DUMP) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
+      }
+      const int b0 = p.ptr[i] - o0;
+      for (int b = b0; b <= tid; b++) {
+        const int jb = sJ[b];
+        double *Sblk = p.S + (size_t)(6 * ja) * p.nA + 6 * jb;
+        const double *wb = sW + 18 * b;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+            atomicAdd(&Sblk[(size_t)r * p.nA + c],
+                      -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < p.nA; t += TILE_OBS)
+    if (sEa[t] != 0.0) atomicAdd(&p.ea[t], sEa[t]);
+}
+
+// S += blockdiag(U) + mu_add I on the lower block triangle, mirror to the upper block
+// triangle, ea += g_a.  mu_add is mu on rank 0 and 0 elsewhere so that the all-reduce of
+// the per-rank contributions adds mu exactly once.
+__global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, const double *U,
+                                                        const double *ga, double mu_add, int nA) {
+  const size_t n2 = (size_t)nA * nA;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n2;
+       t += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / nA), c = (int)(t % nA);
+    const int kb = r / 6, lb = c / 6;
+    if (lb > kb) {
+      S[t] = S[(size_t)c * nA + r];
+    } else if (lb == kb) {
+      double v = S[t] + U[36 * kb + 6 * (r - 6 * kb) + (c - 6 * lb)];
+      if (r == c) v += mu_add;
+      S[t] = v;
+    }
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nA; t += gridDim.x * blockDim.x)
+    ea[t] += ga[t];
+}
+
+int launch_schur(psba_ctx *h, double mu, bool dump) {
+  const Dims &d = h->d;
+  SchurArgs a;
+  a.W = h->W;
+  a.PV = h->PV;
+  a.iidx = h->iidx;
+  a.jidx = h->jidx;
+  a.ptr = h->ptr;
+  a.tile_pt = h->tile_pt;
+  a.S = h->red;
+  a.ea = h->red + (size_t)d.nA * d.nA;
+  a.status = h->status;
+  a.dbg_Y = h->dbg_Y;
+  a.dbg_Vinv = h->dbg_Vinv;
+  a.mu = mu;
+  a.nC = d.nC;
+  a.nA = d.nA;
+  a.nTiles = d.nTiles;
+  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * ((size_t)d.nA * d.nA + d.nA), h->stream));
+  PSBA_HIP(h, hipMemsetAsync(h->status, 0, sizeof(int) * 4, h->stream));
+  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  const size_t lds = sizeof(double) * (size_t)d.nA;
+  {
+    ProfScope ps(h, PSBA_K_SCHUR);
+    if (dump)
+      hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+  }
+  const double mu_add = h->rank == 0 ? mu : 0.0;
+  size_t n2 = (size_t)d.nA * d.nA;
+  int fgrid = (int)((n2 + 255) / 256);
+  if (fgrid > 1024) fgrid = 1024;
+  hipLaunchKernelGGL(k_schur_finalize, dim3(fgrid), dim3(256), 0, h->stream, a.S, a.ea, h->U, h->ga,
+                     mu_add, d.nA);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+}  // namespace psba

@@ -1,0 +1,738 @@
+// psba_api.cpp -- the thin C-ABI HIP host layer (include/psba_hip.h).
+// Takes the place of PSBA/cl_psba.cpp (runtime, buffers, uploads), PSBA/sba_func.cpp (one
+// host wrapper per kernel), PSBA/cl_spdinv.cpp + PSBA/cl_linearalg.cpp (dense solve) and
+// PSBA/misc.cpp:178-217 (index generation) of the reference.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "psba_internal.h"
+
+using namespace psba;
+
+static thread_local std::string g_create_err;
+
+namespace psba {
+
+int fail(psba_ctx *h, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h)
+    h->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+ProfScope::ProfScope(psba_ctx *hh, int kind) : h(hh) {
+  if (!h->prof) return;
+  if (h->spans_used == h->spans.size()) {
+    psba_ctx::Span s;
+    s.kind = kind;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    h->spans.push_back(s);
+  }
+  idx = (int)h->spans_used++;
+  h->spans[idx].kind = kind;
+  (void)hipEventRecord(h->spans[idx].a, h->stream);
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(h->spans[idx].b, h->stream);
+}
+
+}  // namespace psba
+
+#define CHECK_H(h)                 \
+  do {                             \
+    if (!(h)) return PSBA_E_INVALID; \
+  } while (0)
+#define NEED(h, cond, what)                                             \
+  do {                                                                  \
+    if (!(cond)) return fail((h), PSBA_E_STATE, "%s: %s", __func__, what); \
+  } while (0)
+#define RCCL(h, call)                                                                   \
+  do {                                                                                  \
+    ncclResult_t r__ = (call);                                                          \
+    if (r__ != ncclSuccess)                                                             \
+      return fail((h), PSBA_E_RCCL, "%s failed: %s", #call, ncclGetErrorString(r__));   \
+  } while (0)
+#define TRY(expr)                 \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ < 0) return rc__;    \
+  } while (0)
+
+template <typename T>
+static int dev_alloc(psba_ctx *h, T **p, size_t n) {
+  PSBA_HIP(h, hipMalloc((void **)p, sizeof(T) * (n ? n : 1)));
+  return PSBA_OK;
+}
+template <typename T>
+static void dev_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+static void free_problem_buffers(psba_ctx *h) {
+  dev_free(h->camconst);
+  dev_free(h->cams[0]);
+  dev_free(h->cams[1]);
+  dev_free(h->pts[0]);
+  dev_free(h->pts[1]);
+  dev_free(h->impts);
+  dev_free(h->iidx);
+  dev_free(h->jidx);
+  dev_free(h->ptr);
+  dev_free(h->tile_pt);
+  dev_free(h->W);
+  dev_free(h->PV);
+  dev_free(h->U);
+  dev_free(h->ga);
+  dev_free(h->campart);
+  dev_free(h->red);
+  dev_free(h->dp);
+  dev_free(h->dbg_ex);
+  dev_free(h->dbg_JA);
+  dev_free(h->dbg_JB);
+  dev_free(h->dbg_Y);
+  dev_free(h->dbg_Vinv);
+  dev_free(h->dbg_eb);
+  h->uploaded = h->linearized = h->assembled = h->solved = h->backsubbed = false;
+}
+
+extern "C" {
+
+const char *psba_version(void) { return "psba_hip 0.1 (gfx950, fp64)"; }
+
+const char *psba_last_error(psba_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int psba_create(int device, psba_handle *out) {
+  if (!out) return PSBA_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, PSBA_E_HIP, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return fail(nullptr, PSBA_E_INVALID, "device %d out of range (%d devices)", device, ndev);
+  psba_ctx *h = new psba_ctx();
+  h->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc((void **)&h->scal, sizeof(double) * NSCAL)) != hipSuccess ||
+      (e = hipMalloc((void **)&h->status, sizeof(int) * 4)) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * NSCAL)) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_status, sizeof(int) * 4)) != hipSuccess) {
+    int rc = fail(nullptr, PSBA_E_HIP, "psba_create: %s", hipGetErrorString(e));
+    delete h;
+    return rc;
+  }
+  (void)hipMemset(h->scal, 0, sizeof(double) * NSCAL);
+  (void)hipMemset(h->status, 0, sizeof(int) * 4);
+  *out = h;
+  return PSBA_OK;
+}
+
+int psba_destroy(psba_handle h) {
+  CHECK_H(h);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) ncclCommDestroy(h->comm);
+  free_problem_buffers(h);
+  dev_free(h->scal);
+  dev_free(h->status);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->h_status) (void)hipHostFree(h->h_status);
+  for (auto &s : h->spans) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PSBA_OK;
+}
+
+int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (nCams) *nCams = h->d.nC;
+  if (n3Dpts) *n3Dpts = h->d.nP;
+  if (n2Dprojs) *n2Dprojs = h->d.nO;
+  return PSBA_OK;
+}
+
+int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, const double *Kparas,
+                        const double *impts, const double *initrot, const double *camsEx,
+                        const double *pts3D, const int *iidx, const int *jidx) {
+  CHECK_H(h);
+  if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !Kparas || !impts || !initrot || !camsEx ||
+      !pts3D || !iidx || !jidx)
+    return fail(h, PSBA_E_INVALID, "psba_upload_problem: null pointer or non-positive size");
+  PSBA_HIP(h, hipSetDevice(h->device));
+  // ---- index build: point CSR + point-aligned tiles (replaces generate_idxs) ----
+  std::vector<int> ptr((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    const int i = iidx[a], j = jidx[a];
+    if (i < 0 || i >= n3Dpts || j < 0 || j >= nCams)
+      return fail(h, PSBA_E_INVALID, "observation %d: point %d / camera %d out of range", a, i, j);
+    if (a > 0 && (i < iidx[a - 1] || (i == iidx[a - 1] && j <= jidx[a - 1])))
+      return fail(h, PSBA_E_INVALID,
+                  "observations must be sorted point-major with ascending, distinct cameras "
+                  "inside a point (violated at observation %d)", a);
+    ptr[(size_t)i + 1]++;
+  }
+  int maxTrack = 0;
+  for (int i = 0; i < n3Dpts; i++) {
+    if (ptr[(size_t)i + 1] > maxTrack) maxTrack = ptr[(size_t)i + 1];
+    ptr[(size_t)i + 1] += ptr[i];
+  }
+  if (maxTrack > TILE_OBS)
+    return fail(h, PSBA_E_INVALID, "a point is seen by %d cameras; at most %d supported", maxTrack,
+                TILE_OBS);
+  std::vector<int> tile_pt;
+  tile_pt.push_back(0);
+  {
+    int p0 = 0;
+    while (p0 < n3Dpts) {
+      int p1 = p0;
+      while (p1 < n3Dpts && (ptr[(size_t)p1 + 1] - ptr[p0]) <= TILE_OBS && (p1 - p0) < TILE_OBS) p1++;
+      tile_pt.push_back(p1);
+      p0 = p1;
+    }
+  }
+  free_problem_buffers(h);
+  Dims d;
+  d.nC = nCams;
+  d.nP = n3Dpts;
+  d.nO = n2Dprojs;
+  d.nA = 6 * nCams;
+  d.nB = 3 * n3Dpts;
+  d.nT = d.nA + d.nB;
+  d.nTiles = (int)tile_pt.size() - 1;
+  d.maxTrack = maxTrack;
+  if ((size_t)CAM_ACC * nCams * sizeof(double) > 96 * 1024)
+    return fail(h, PSBA_E_INVALID, "nCams = %d needs %zu B of LDS camera accumulators; > 96 KiB "
+                "not supported yet", nCams, (size_t)CAM_ACC * nCams * sizeof(double));
+  h->d = d;
+  h->nPart = d.nTiles < 512 ? d.nTiles : 512;
+  h->cur = 0;
+
+  std::vector<double> cc((size_t)nCams * 9);
+  for (int j = 0; j < nCams; j++) {
+    for (int k = 0; k < 5; k++) cc[(size_t)9 * j + k] = Kparas[5 * j + k];
+    for (int k = 0; k < 4; k++) cc[(size_t)9 * j + 5 + k] = initrot[4 * j + k];
+  }
+  TRY(dev_alloc(h, &h->camconst, cc.size()));
+  TRY(dev_alloc(h, &h->cams[0], (size_t)d.nA));
+  TRY(dev_alloc(h, &h->cams[1], (size_t)d.nA));
+  TRY(dev_alloc(h, &h->pts[0], (size_t)d.nB));
+  TRY(dev_alloc(h, &h->pts[1], (size_t)d.nB));
+  TRY(dev_alloc(h, &h->impts, (size_t)2 * d.nO));
+  TRY(dev_alloc(h, &h->iidx, (size_t)d.nO));
+  TRY(dev_alloc(h, &h->jidx, (size_t)d.nO));
+  TRY(dev_alloc(h, &h->ptr, (size_t)d.nP + 1));
+  TRY(dev_alloc(h, &h->tile_pt, tile_pt.size()));
+  TRY(dev_alloc(h, &h->W, (size_t)18 * d.nO));
+  TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
+  TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
+  TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
+  TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
+  TRY(dev_alloc(h, &h->red, (size_t)d.nA * d.nA + d.nA));
+  TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
+  auto H2D = [&](void *dst, const void *src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+  };
+  PSBA_HIP(h, H2D(h->camconst, cc.data(), sizeof(double) * cc.size()));
+  PSBA_HIP(h, H2D(h->cams[0], camsEx, sizeof(double) * d.nA));
+  PSBA_HIP(h, H2D(h->pts[0], pts3D, sizeof(double) * d.nB));
+  PSBA_HIP(h, H2D(h->impts, impts, sizeof(double) * 2 * (size_t)d.nO));
+  PSBA_HIP(h, H2D(h->iidx, iidx, sizeof(int) * (size_t)d.nO));
+  PSBA_HIP(h, H2D(h->jidx, jidx, sizeof(int) * (size_t)d.nO));
+  PSBA_HIP(h, H2D(h->ptr, ptr.data(), sizeof(int) * ptr.size()));
+  PSBA_HIP(h, H2D(h->tile_pt, tile_pt.data(), sizeof(int) * tile_pt.size()));
+  PSBA_HIP(h, hipMemsetAsync(h->dp, 0, sizeof(double) * d.nT, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
+  h->uploaded = true;
+  return PSBA_OK;
+}
+
+int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  PSBA_HIP(h, hipMemcpyAsync(h->cams[h->cur], camsEx, sizeof(double) * h->d.nA,
+                             hipMemcpyHostToDevice, h->stream));
+  PSBA_HIP(h, hipMemcpyAsync(h->pts[h->cur], pts3D, sizeof(double) * h->d.nB,
+                             hipMemcpyHostToDevice, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  h->linearized = h->assembled = h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  const int set = which == PSBA_PARAMS_NEW ? 1 - h->cur : h->cur;
+  if (camsEx)
+    PSBA_HIP(h, hipMemcpyAsync(camsEx, h->cams[set], sizeof(double) * h->d.nA,
+                               hipMemcpyDeviceToHost, h->stream));
+  if (pts3D)
+    PSBA_HIP(h, hipMemcpyAsync(pts3D, h->pts[set], sizeof(double) * h->d.nB,
+                               hipMemcpyDeviceToHost, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  return PSBA_OK;
+}
+
+// ---- fused verbs ------------------------------------------------------------------------
+
+static int fetch_scalars(psba_ctx *h) {
+  PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost,
+                             h->stream));
+  PSBA_HIP(h, hipMemcpyAsync(h->h_status, h->status, sizeof(int) * 4, hipMemcpyDeviceToHost,
+                             h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  return PSBA_OK;
+}
+
+int psba_residual(psba_handle h, int which, double *cost) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  TRY(launch_residual(h, which, nullptr));
+  if (h->comm)
+    RCCL(h, ncclAllReduce(h->scal + SC_COST, h->scal + SC_COST, 1, ncclDouble, ncclSum, h->comm,
+                          h->stream));
+  TRY(fetch_scalars(h));
+  if (cost) *cost = h->h_scal[SC_COST];
+  return PSBA_OK;
+}
+
+int psba_linearize(psba_handle h, double coeff, double coeff_g) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  h->coeff = coeff;
+  h->coeff_g = coeff_g;
+  TRY(launch_linearize(h, false));
+  h->linearized = true;
+  h->assembled = h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+int psba_max_diag(psba_handle h, double *out) {
+  CHECK_H(h);
+  NEED(h, h->linearized, "psba_linearize first");
+  if (h->comm) {
+    // diag(U) is a sum over all points: reduce the per-rank U first (scratch copy in dp)
+    double *tmp = h->dp;  // dp is free between linearize and the first solve
+    PSBA_HIP(h, hipMemcpyAsync(tmp, h->U, sizeof(double) * 36 * h->d.nC, hipMemcpyDeviceToDevice,
+                               h->stream));
+    RCCL(h, ncclAllReduce(tmp, tmp, (size_t)36 * h->d.nC, ncclDouble, ncclSum, h->comm, h->stream));
+    double *keep = h->U;
+    h->U = tmp;
+    int rc = launch_max_diag(h);
+    h->U = keep;
+    TRY(rc);
+    RCCL(h, ncclAllReduce(h->scal + SC_MAXDIAG, h->scal + SC_MAXDIAG, 1, ncclDouble, ncclMax,
+                          h->comm, h->stream));
+  } else {
+    TRY(launch_max_diag(h));
+  }
+  TRY(fetch_scalars(h));
+  if (out) *out = h->h_scal[SC_MAXDIAG];
+  return PSBA_OK;
+}
+
+int psba_schur_assemble(psba_handle h, double mu) {
+  CHECK_H(h);
+  NEED(h, h->linearized, "psba_linearize first");
+  h->mu = mu;
+  TRY(launch_schur(h, mu, false));
+  h->assembled = true;
+  h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+int psba_schur_reduce(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  if (!h->comm) return PSBA_OK;
+  ProfScope ps(h, PSBA_K_ALLREDUCE);
+  const size_t n = (size_t)h->d.nA * h->d.nA + h->d.nA;
+  RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
+  return PSBA_OK;
+}
+
+int psba_schur_solve(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  TRY(launch_chol_solve(h));
+  h->assembled = false;  // S is overwritten by its factor
+  h->solved = true;
+  return PSBA_OK;
+}
+
+int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
+  CHECK_H(h);
+  NEED(h, h->solved, "psba_schur_solve first");
+  TRY(launch_backsub(h, mu, false));
+  if (h->comm) {
+    RCCL(h, ncclAllReduce(h->scal + SC_DP_L2, h->scal + SC_DP_L2, 4, ncclDouble, ncclSum, h->comm,
+                          h->stream));
+    RCCL(h, ncclAllReduce(h->status, h->status, 4, ncclInt, ncclMax, h->comm, h->stream));
+  }
+  TRY(fetch_scalars(h));
+  h->backsubbed = true;
+  if (out) {
+    out->status = (h->h_status[1] ? PSBA_NOT_SPD : 0) | (h->h_status[0] ? PSBA_SINGULAR_V : 0);
+    out->dp_l2 = h->h_scal[SC_DP_L2];
+    out->gain_den = h->h_scal[SC_GAIN_DEN];
+    out->new_cost = h->h_scal[SC_NEW_COST];
+    out->newp_l2 = h->h_scal[SC_NEWP_L2];
+  }
+  return PSBA_OK;
+}
+
+int psba_accept(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->backsubbed, "psba_backsub first");
+  h->cur = 1 - h->cur;
+  h->linearized = h->assembled = h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+// ---- sba_func.h mirror ------------------------------------------------------------------
+
+static int ensure_dbg(psba_ctx *h) {
+  const Dims &d = h->d;
+  if (!h->dbg_ex) TRY(dev_alloc(h, &h->dbg_ex, (size_t)2 * d.nO));
+  if (!h->dbg_JA) TRY(dev_alloc(h, &h->dbg_JA, (size_t)12 * d.nO));
+  if (!h->dbg_JB) TRY(dev_alloc(h, &h->dbg_JB, (size_t)6 * d.nO));
+  if (!h->dbg_Y) TRY(dev_alloc(h, &h->dbg_Y, (size_t)18 * d.nO));
+  if (!h->dbg_Vinv) TRY(dev_alloc(h, &h->dbg_Vinv, (size_t)9 * d.nP));
+  if (!h->dbg_eb) TRY(dev_alloc(h, &h->dbg_eb, (size_t)3 * d.nP));
+  return PSBA_OK;
+}
+
+static int d2h(psba_ctx *h, void *dst, const void *src, size_t bytes) {
+  if (!dst) return PSBA_OK;
+  PSBA_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  return PSBA_OK;
+}
+
+static int relinearize_dump(psba_ctx *h) {
+  TRY(ensure_dbg(h));
+  TRY(launch_linearize(h, true));
+  h->linearized = true;
+  h->assembled = h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+static int reassemble_dump(psba_ctx *h) {
+  NEED(h, h->linearized, "linearise first (compute_jacobiQT / compute_U / ...)");
+  TRY(ensure_dbg(h));
+  TRY(launch_schur(h, h->mu_applied ? h->mu : 0.0, true));
+  h->assembled = true;
+  h->solved = h->backsubbed = false;
+  if (h->comm) {
+    const size_t n = (size_t)h->d.nA * h->d.nA + h->d.nA;
+    RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
+  }
+  return PSBA_OK;
+}
+
+int psba_compute_exQT(psba_handle h, int which, double *ex) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  TRY(ensure_dbg(h));
+  TRY(launch_residual(h, which, h->dbg_ex));
+  return d2h(h, ex, h->dbg_ex, sizeof(double) * 2 * (size_t)h->d.nO);
+}
+
+int psba_compute_jacobiQT(psba_handle h, double *jac_A, double *jac_B) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  TRY(relinearize_dump(h));
+  TRY(d2h(h, jac_A, h->dbg_JA, sizeof(double) * 12 * (size_t)h->d.nO));
+  return d2h(h, jac_B, h->dbg_JB, sizeof(double) * 6 * (size_t)h->d.nO);
+}
+
+int psba_compute_U(psba_handle h, double coeff, double *out) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  h->coeff = coeff;
+  TRY(relinearize_dump(h));
+  return d2h(h, out, h->U, sizeof(double) * 36 * (size_t)h->d.nC);
+}
+
+static int download_V(psba_ctx *h, double *out, double mu) {
+  if (!out) return PSBA_OK;
+  std::vector<double> pv((size_t)9 * h->d.nP);
+  TRY(d2h(h, pv.data(), h->PV, sizeof(double) * pv.size()));
+  for (int i = 0; i < h->d.nP; i++) {
+    const double *s = &pv[(size_t)9 * i];
+    double *o = out + (size_t)9 * i;
+    o[0] = s[0] + mu; o[1] = s[1]; o[2] = s[2];
+    o[3] = s[1]; o[4] = s[3] + mu; o[5] = s[4];
+    o[6] = s[2]; o[7] = s[4]; o[8] = s[5] + mu;
+  }
+  return PSBA_OK;
+}
+
+int psba_compute_V(psba_handle h, double coeff, double *out) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  h->coeff = coeff;
+  TRY(relinearize_dump(h));
+  return download_V(h, out, 0.0);
+}
+
+int psba_maxElmOfUV(psba_handle h, double *out) { return psba_max_diag(h, out); }
+
+int psba_update_UV(psba_handle h, double mu, double *U, double *V) {
+  CHECK_H(h);
+  NEED(h, h->linearized, "linearise first");
+  h->mu = mu;
+  h->mu_applied = true;
+  if (U) {
+    TRY(d2h(h, U, h->U, sizeof(double) * 36 * (size_t)h->d.nC));
+    for (int t = 0; t < h->d.nA; t++) U[36 * (t / 6) + 7 * (t % 6)] += mu;
+  }
+  return download_V(h, V, mu);
+}
+
+int psba_restore_UVdiag(psba_handle h) {
+  CHECK_H(h);
+  h->mu_applied = false;
+  return PSBA_OK;
+}
+
+int psba_compute_Vinv(psba_handle h, double *Vinv) {
+  CHECK_H(h);
+  TRY(reassemble_dump(h));
+  TRY(d2h(h, Vinv, h->dbg_Vinv, sizeof(double) * 9 * (size_t)h->d.nP));
+  TRY(fetch_scalars(h));
+  return h->h_status[0] ? PSBA_SINGULAR_V : PSBA_OK;
+}
+
+int psba_compute_Wblks(psba_handle h, double coeff, double *Wblks) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  h->coeff = coeff;
+  TRY(relinearize_dump(h));
+  return d2h(h, Wblks, h->W, sizeof(double) * 18 * (size_t)h->d.nO);
+}
+
+int psba_compute_Yblks(psba_handle h, double *Yblks) {
+  CHECK_H(h);
+  TRY(reassemble_dump(h));
+  return d2h(h, Yblks, h->dbg_Y, sizeof(double) * 18 * (size_t)h->d.nO);
+}
+
+int psba_compute_S(psba_handle h, double *S) {
+  CHECK_H(h);
+  TRY(reassemble_dump(h));
+  return d2h(h, S, h->red, sizeof(double) * (size_t)h->d.nA * h->d.nA);
+}
+
+int psba_compute_g(psba_handle h, double coeff, double *g) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  h->coeff_g = coeff;
+  TRY(relinearize_dump(h));
+  if (!g) return PSBA_OK;
+  TRY(d2h(h, g, h->ga, sizeof(double) * (size_t)h->d.nA));
+  std::vector<double> pv((size_t)9 * h->d.nP);
+  TRY(d2h(h, pv.data(), h->PV, sizeof(double) * pv.size()));
+  for (int i = 0; i < h->d.nP; i++)
+    for (int k = 0; k < 3; k++) g[h->d.nA + 3 * (size_t)i + k] = pv[(size_t)9 * i + 6 + k];
+  return PSBA_OK;
+}
+
+int psba_compute_ea(psba_handle h, double *ea) {
+  CHECK_H(h);
+  TRY(reassemble_dump(h));
+  return d2h(h, ea, h->red + (size_t)h->d.nA * h->d.nA, sizeof(double) * (size_t)h->d.nA);
+}
+
+int psba_SPDinv_matVec(psba_handle h, double *dpa) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "compute_S / compute_ea first");
+  TRY(launch_chol_solve(h));
+  h->assembled = false;
+  h->solved = true;
+  TRY(fetch_scalars(h));
+  TRY(d2h(h, dpa, h->dp, sizeof(double) * (size_t)h->d.nA));
+  return h->h_status[1] ? PSBA_NOT_SPD : PSBA_OK;
+}
+
+static int backsub_dump(psba_ctx *h) {
+  NEED(h, h->solved, "SPDinv_matVec first");
+  TRY(ensure_dbg(h));
+  TRY(launch_backsub(h, h->mu_applied ? h->mu : 0.0, true));
+  h->backsubbed = true;
+  return PSBA_OK;
+}
+
+int psba_compute_eb(psba_handle h, double *eb) {
+  CHECK_H(h);
+  TRY(backsub_dump(h));
+  return d2h(h, eb, h->dbg_eb, sizeof(double) * 3 * (size_t)h->d.nP);
+}
+
+int psba_compute_dpb(psba_handle h, double *dp) {
+  CHECK_H(h);
+  TRY(backsub_dump(h));
+  return d2h(h, dp, h->dp, sizeof(double) * (size_t)h->d.nT);
+}
+
+int psba_compute_newp(psba_handle h, double *new_p) {
+  CHECK_H(h);
+  NEED(h, h->backsubbed, "compute_dpb first");
+  if (!new_p) return PSBA_OK;
+  TRY(d2h(h, new_p, h->cams[1 - h->cur], sizeof(double) * (size_t)h->d.nA));
+  return d2h(h, new_p + h->d.nA, h->pts[1 - h->cur], sizeof(double) * (size_t)h->d.nB);
+}
+
+int psba_update_p(psba_handle h, double *p) {
+  CHECK_H(h);
+  TRY(psba_accept(h));
+  if (!p) return PSBA_OK;
+  TRY(d2h(h, p, h->cams[h->cur], sizeof(double) * (size_t)h->d.nA));
+  return d2h(h, p + h->d.nA, h->pts[h->cur], sizeof(double) * (size_t)h->d.nB);
+}
+
+// ---- multi-GPU --------------------------------------------------------------------------
+
+int psba_partition_points(int n3Dpts, const int *iidx, int n2Dprojs, int nranks, int *pt_begin) {
+  if (n3Dpts <= 0 || nranks <= 0 || !iidx || !pt_begin || n2Dprojs < 0) return PSBA_E_INVALID;
+  // contiguous point ranges; rank r ends at the first point whose cumulative observation
+  // count reaches (r+1)/nranks of the total
+  std::vector<long long> cum((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    if (iidx[a] < 0 || iidx[a] >= n3Dpts) return PSBA_E_INVALID;
+    cum[(size_t)iidx[a] + 1]++;
+  }
+  for (int i = 0; i < n3Dpts; i++) cum[(size_t)i + 1] += cum[i];
+  pt_begin[0] = 0;
+  int p = 0;
+  for (int r = 1; r < nranks; r++) {
+    const long long target = (long long)n2Dprojs * r / nranks;
+    while (p < n3Dpts && cum[p] < target) p++;
+    // keep at least one point per rank when there are enough points
+    int lo = pt_begin[r - 1] + 1, hi = n3Dpts - (nranks - r);
+    if (n3Dpts >= nranks) {
+      if (p < lo) p = lo;
+      if (p > hi) p = hi;
+    }
+    pt_begin[r] = p;
+  }
+  pt_begin[nranks] = n3Dpts;
+  return PSBA_OK;
+}
+
+int psba_comm_unique_id(void *id128) {
+  if (!id128) return PSBA_E_INVALID;
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return PSBA_E_RCCL;
+  memcpy(id128, &id, sizeof id);
+  return PSBA_OK;
+}
+
+int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128) {
+  CHECK_H(h);
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id128)
+    return fail(h, PSBA_E_INVALID, "psba_comm_init: bad rank %d / %d", rank, nranks);
+  PSBA_HIP(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  RCCL(h, ncclCommInitRank(&h->comm, nranks, id, rank));
+  h->nranks = nranks;
+  h->rank = rank;
+  return PSBA_OK;
+}
+
+int psba_comm_rank(psba_handle h, int *nranks, int *rank) {
+  CHECK_H(h);
+  if (nranks) *nranks = h->nranks;
+  if (rank) *rank = h->rank;
+  return PSBA_OK;
+}
+
+// ---- measurement ------------------------------------------------------------------------
+
+static int prof_flush(psba_ctx *h) {
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  for (size_t k = 0; k < h->spans_used; k++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->spans[k].a, h->spans[k].b) == hipSuccess) {
+      h->prof_ms[h->spans[k].kind] += ms;
+      h->prof_n[h->spans[k].kind]++;
+    }
+  }
+  h->spans_used = 0;
+  return PSBA_OK;
+}
+
+int psba_profile_enable(psba_handle h, int on) {
+  CHECK_H(h);
+  TRY(prof_flush(h));
+  h->prof = on != 0;
+  return PSBA_OK;
+}
+
+int psba_profile_reset(psba_handle h) {
+  CHECK_H(h);
+  TRY(prof_flush(h));
+  for (int k = 0; k < PSBA_K_COUNT; k++) {
+    h->prof_ms[k] = 0;
+    h->prof_n[k] = 0;
+  }
+  return PSBA_OK;
+}
+
+int psba_profile_get(psba_handle h, int kernel, double *total_ms, int *launches) {
+  CHECK_H(h);
+  if (kernel < 0 || kernel >= PSBA_K_COUNT) return fail(h, PSBA_E_INVALID, "bad kernel class");
+  TRY(prof_flush(h));
+  if (total_ms) *total_ms = h->prof_ms[kernel];
+  if (launches) *launches = h->prof_n[kernel];
+  return PSBA_OK;
+}
+
+int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  const double nO = h->d.nO, nP = h->d.nP, nC = h->d.nC, nA = h->d.nA;
+  double b = 0;
+  switch (kernel) {
+    case PSBA_K_LINEARIZE:
+      b = nO * (16 + 8 + 144) + nP * (24 + 72 + 24) + nC * (120 + 288 + 48);
+      break;
+    case PSBA_K_SCHUR:  // SURVEY 8(d) K2, S counted once as the full square
+      b = nO * (144 + 8) + nP * (72 + 24) + nC * (288 + 48) + 8 * nA * nA + 8 * nA;
+      break;
+    case PSBA_K_BACKSUB:  // SURVEY 8(d) K3 incl. the fused new-cost pass
+      b = nO * 152 + nP * (72 + 24 + 24 + 24) + nA * 8 + nO * 24 + 8;
+      break;
+    case PSBA_K_CHOLESKY:
+      b = 8 * nA * nA;
+      break;
+    case PSBA_K_RESIDUAL:
+      b = nO * 24 + nP * 24 + nC * 120 + 8;
+      break;
+    default:
+      return fail(h, PSBA_E_INVALID, "no byte model for kernel class %d", kernel);
+  }
+  if (bytes) *bytes = b;
+  return PSBA_OK;
+}
+
+}  // extern "C"

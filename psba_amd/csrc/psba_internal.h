@@ -1,0 +1,119 @@
+// psba_internal.h -- the handle behind include/psba_hip.h and the kernel launch prototypes.
+// Takes the place of PSBA_struct (reference PSBA/cl_psba.h:9-89) and the 31 cl_mem
+// allocations of setup_cl (PSBA/cl_psba.cpp:40-84).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/psba_hip.h"
+
+namespace psba {
+
+constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= threads per workgroup)
+constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
+constexpr int NSCAL = 16;       // device scalar block (doubles)
+
+// slots of the device scalar block
+enum {
+  SC_COST = 0,      // ||e||^2 of psba_residual
+  SC_DP_L2 = 1,
+  SC_GAIN_DEN = 2,
+  SC_NEW_COST = 3,
+  SC_NEWP_L2 = 4,
+  SC_MAXDIAG = 5,
+};
+
+struct Dims {
+  int nC = 0, nP = 0, nO = 0;
+  int nA = 0, nB = 0, nT = 0;
+  int nTiles = 0;
+  int maxTrack = 0;
+};
+
+}  // namespace psba
+
+struct psba_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  psba::Dims d;
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+
+  // ---- device memory (all owned here) ----
+  double *camconst = nullptr;   // [nC][9]  K5 | q0(4)               (Kparas_buffer, initcams_buffer)
+  double *cams[2] = {nullptr, nullptr};  // [nC][6] cur / proposed   (cams_buffer, newCams_buffer)
+  double *pts[2] = {nullptr, nullptr};   // [nP][3] cur / proposed   (pts3D_buffer, newPts3D_buffer)
+  double *impts = nullptr;      // [nO][2]                           (impts_buffer)
+  int *iidx = nullptr;          // [nO] point of each observation    (iidx_buffer)
+  int *jidx = nullptr;          // [nO] camera of each observation   (jidx_buffer)
+  int *ptr = nullptr;           // [nP+1] point CSR over observations (replaces blkIdx_buffer)
+  int *tile_pt = nullptr;       // [nTiles+1] first point of each tile
+  double *W = nullptr;          // [nO][18] W_ij = coeff A^T B        (W_buffer)
+  double *PV = nullptr;         // [nP][9]  V_i sym6 | g_b,i          (V_buffer + g_buffer tail)
+  double *U = nullptr;          // [nC][36]                           (U_buffer)
+  double *ga = nullptr;         // [nA]                               (g_buffer head)
+  double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
+  int nPart = 0;
+  double *red = nullptr;        // [nA*nA + nA]  S | ea, the all-reduce buffer (S_buffer, eab_buffer)
+  double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
+  double *scal = nullptr;       // [NSCAL]
+  int *status = nullptr;        // [4]  [0]=singular V, [1]=not SPD
+  double *h_scal = nullptr;     // pinned mirror of scal
+  int *h_status = nullptr;      // pinned mirror of status
+  // debug dumps for the sba_func.h mirror (allocated on first use)
+  double *dbg_ex = nullptr, *dbg_JA = nullptr, *dbg_JB = nullptr, *dbg_Y = nullptr,
+         *dbg_Vinv = nullptr, *dbg_eb = nullptr;
+
+  // ---- state ----
+  bool uploaded = false, linearized = false, assembled = false, solved = false, backsubbed = false;
+  int cur = 0;                  // index of the current parameter set in cams[]/pts[]
+  double coeff = 1.0, coeff_g = 1.0, mu = 0.0;
+  bool mu_applied = false;      // update_UV called (fine-grained mirror only)
+
+  // ---- profiling ----
+  bool prof = false;
+  struct Span { hipEvent_t a, b; int kind; };
+  std::vector<Span> spans;
+  size_t spans_used = 0;
+  double prof_ms[PSBA_K_COUNT] = {0};
+  int prof_n[PSBA_K_COUNT] = {0};
+};
+
+namespace psba {
+
+// error helpers (psba_api.cpp)
+int fail(psba_ctx *h, int code, const char *fmt, ...);
+#define PSBA_HIP(h, call)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return psba::fail((h), PSBA_E_HIP, "%s failed: %s (%s:%d)", #call,               \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                   \
+  } while (0)
+
+struct ProfScope {
+  psba_ctx *h;
+  int idx = -1;
+  ProfScope(psba_ctx *h, int kind);
+  ~ProfScope();
+};
+
+// ---- kernel launchers (one per .hip file) ----
+// kernels_linearize.hip
+int launch_linearize(psba_ctx *h, bool dump);
+int launch_residual(psba_ctx *h, int which, double *ex_out_dev);
+int launch_max_diag(psba_ctx *h);
+// kernels_schur.hip
+int launch_schur(psba_ctx *h, double mu, bool dump);
+// kernels_chol.hip
+int launch_chol_solve(psba_ctx *h);
+// kernels_backsub.hip
+int launch_backsub(psba_ctx *h, double mu, bool dump);
+
+}  // namespace psba

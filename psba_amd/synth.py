@@ -1,0 +1,109 @@
+"""Synthetic bundle-adjustment problems in the reference's parameterisation (host-side
+workload generator for bench.py and tests; not part of the GPU path).
+
+SURVEY.md section 8(d): the real Venice-52-64053 / Trafalgar-50-20431 point files are missing
+from the reference checkout, so the benchmark uses *shaped* stand-ins: the named number of
+cameras and points, track length k ~ min_track + Geometric with the named mean, k distinct
+cameras drawn uniformly, points placed in front of their cameras, observations = projection of
+the true point + N(0, 1 px), initial parameters = truth + small perturbation.  Every result made
+with this generator is labelled "synthetic-shaped", never with the dataset's name alone.
+"""
+import numpy as np
+
+from .capi import Problem
+
+
+def _quat_mul(a, b):
+    """Hamilton product of scalar-first quaternions, broadcasting."""
+    s = a[..., 0] * b[..., 0] - (a[..., 1:] * b[..., 1:]).sum(-1)
+    v = a[..., :1] * b[..., 1:] + b[..., :1] * a[..., 1:] + np.cross(a[..., 1:], b[..., 1:])
+    return np.concatenate([s[..., None], v], -1)
+
+
+def _rotate(q, M):
+    u, s = q[..., 1:], q[..., :1]
+    w = s * M + np.cross(u, M)
+    return (u * M).sum(-1, keepdims=True) * u + s * w + np.cross(u, w)
+
+
+def project(K, q0, cams, M):
+    """Projection model of the reference for matching rows of
+    K[.,5], q0[.,4], cams[.,6], M[.,3]."""
+    v = cams[..., :3]
+    ql = np.concatenate([np.sqrt(1.0 - (v * v).sum(-1, keepdims=True)), v], -1)
+    P = _rotate(_quat_mul(ql, q0), M) + cams[..., 3:]
+    x = (K[..., 0] * P[..., 0] + K[..., 4] * P[..., 1] + K[..., 1] * P[..., 2]) / P[..., 2]
+    y = (K[..., 0] * K[..., 3] * P[..., 1] + K[..., 2] * P[..., 2]) / P[..., 2]
+    return np.stack([x, y], -1), P[..., 2]
+
+
+def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, noise_px=1.0,
+                 cam_sigma=1e-3, pt_sigma=1e-2, focal=1000.0):
+    """Cameras on a circle of radius 10 looking at the origin; points in the unit ball."""
+    rng = np.random.default_rng(seed)
+    max_track = n_cams if max_track is None else min(max_track, n_cams)
+    # cameras: centre c_j on a circle, rotation taking the world z-axis towards the origin
+    ang = 2 * np.pi * np.arange(n_cams) / n_cams
+    C = np.stack([10 * np.cos(ang), 10 * np.sin(ang), 0.3 * np.sin(3 * ang)], -1)
+    zc = -C / np.linalg.norm(C, axis=1, keepdims=True)
+    up = np.tile([0.0, 0.0, 1.0], (n_cams, 1))
+    xc = np.cross(up, zc)
+    xc /= np.linalg.norm(xc, axis=1, keepdims=True)
+    yc = np.cross(zc, xc)
+    R = np.stack([xc, yc, zc], 1)  # rows = camera axes: P = R (M - C)
+    # rotation matrix -> unit quaternion (scalar first, scalar >= 0), Shepperd's method
+    q = np.empty((n_cams, 4))
+    for j in range(n_cams):
+        m = R[j]
+        cand = [1 + m[0, 0] + m[1, 1] + m[2, 2], 1 + m[0, 0] - m[1, 1] - m[2, 2],
+                1 - m[0, 0] + m[1, 1] - m[2, 2], 1 - m[0, 0] - m[1, 1] + m[2, 2]]
+        c = int(np.argmax(cand))
+        r = np.sqrt(cand[c]) * 2
+        if c == 0:
+            qq = [r / 4, (m[2, 1] - m[1, 2]) / r, (m[0, 2] - m[2, 0]) / r, (m[1, 0] - m[0, 1]) / r]
+        elif c == 1:
+            qq = [(m[2, 1] - m[1, 2]) / r, r / 4, (m[0, 1] + m[1, 0]) / r, (m[0, 2] + m[2, 0]) / r]
+        elif c == 2:
+            qq = [(m[0, 2] - m[2, 0]) / r, (m[0, 1] + m[1, 0]) / r, r / 4, (m[1, 2] + m[2, 1]) / r]
+        else:
+            qq = [(m[1, 0] - m[0, 1]) / r, (m[0, 2] + m[2, 0]) / r, (m[1, 2] + m[2, 1]) / r, r / 4]
+        qq = np.array(qq) / np.linalg.norm(qq)
+        q[j] = qq if qq[0] >= 0 else -qq
+    t = -np.einsum("jrc,jc->jr", R, C)
+    K = np.tile([focal, 0.0, 0.0, 1.0, 0.0], (n_cams, 1))
+    # points uniform in the unit ball
+    M = rng.normal(size=(n_pts, 3))
+    M *= (rng.random(n_pts) ** (1 / 3) / np.linalg.norm(M, axis=1))[:, None]
+    # track lengths: min_track + Geometric, mean matched, capped
+    extra = max(mean_track - min_track, 1e-9)
+    k = min_track + rng.geometric(1.0 / (1.0 + extra), size=n_pts) - 1
+    k = np.clip(k, min_track, max_track)
+    iidx = np.repeat(np.arange(n_pts, dtype=np.int32), k)
+    # k distinct cameras per point, ascending: rank random keys row-wise
+    jidx = np.empty(iidx.size, dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(k)])
+    for kk in np.unique(k):
+        rows = np.nonzero(k == kk)[0]
+        keys = rng.random((rows.size, n_cams))
+        pick = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
+        dest = (off[rows][:, None] + np.arange(kk)[None, :]).reshape(-1)
+        jidx[dest] = pick.reshape(-1)
+    true_cams = np.concatenate([np.zeros((n_cams, 3)), t], 1)
+    xy, depth = project(K[jidx], q[jidx], true_cams[jidx], M[iidx])
+    assert np.all(depth > 0)
+    impts = xy + rng.normal(0, noise_px, xy.shape)
+    cams0 = true_cams + np.concatenate([rng.normal(0, cam_sigma, (n_cams, 3)),
+                                        rng.normal(0, cam_sigma, (n_cams, 3))], 1)
+    pts0 = M + rng.normal(0, pt_sigma, M.shape)
+    return Problem(K=K, initrot=q, cams=cams0, pts=pts0, impts=impts, iidx=iidx, jidx=jidx,
+                   nC=n_cams, nP=n_pts, nO=int(iidx.size))
+
+
+def venice_shaped(n_pts=64053, seed=0x5BA0 + 4):
+    """Venice-52-64053-shaped: 52 cameras, 64053 points, mean track 5.42."""
+    return make_problem(52, n_pts, 5.42, seed)
+
+
+def trafalgar50_shaped(seed=0x5BA0 + 3):
+    """Trafalgar-50-20431-shaped: 50 cameras, 20431 points, mean track 3.62."""
+    return make_problem(50, 20431, 3.62, seed)
