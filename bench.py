@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- ms/LM-iter and M-observations/s through Jacobian + Schur build + solve.
+
+A *step* is one Levenberg-Marquardt outer iteration (one linearisation + all its damping
+tries + their cost evaluations; the unit `itno` counts in reference PSBA/levmar.cpp:100), run by
+the library's own LM loop over the C ABI.  Workload (config.workload):
+  venice-shaped   52 cameras x 64053 points per GPU, mean track 5.42 -- the configuration the
+                  north star quotes its roofline target on; *synthetic-shaped*, because the real
+                  Venice-52-64053 point file is missing from the reference checkout (default)
+  54cams          the reference's data/54cams.txt + 54pts.txt, fixed K (BASELINE configs[1])
+  trafalgar21     the reference's data/Trafalgar-21-11315-*.txt
+Multi-GPU: 3-D points are sharded over ranks (weak scaling: every rank owns one venice-shaped
+shard over the same 52 cameras), [S | ea] is summed with one RCCL all-reduce per damping try.
+Launch for N>1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import psba_amd  # noqa: E402  (loads the HIP library before torch brings its own runtime)
+from psba_amd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def load_workload(name, rank, nranks):
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    if name == "venice-shaped":
+        return synth.venice_shaped(shard=rank), "synthetic"
+    if name == "trafalgar50-shaped":
+        return synth.trafalgar50_shaped(shard=rank), "synthetic"
+    if name == "54cams":
+        kk = np.array([851.57945, 330.24755, 262.19500, 1.00169, 0.0])
+        full = psba_amd.read_problem(os.path.join(data, "54cams.txt"), os.path.join(data, "54pts.txt"), kk)
+    elif name == "trafalgar21":
+        full = psba_amd.read_problem(os.path.join(data, "Trafalgar-21-11315-cams.txt"),
+                                     os.path.join(data, "Trafalgar-21-11315-pts.txt"))
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return (capi.shard_problem(full, nranks, rank) if nranks > 1 else full), "reference data/*.txt"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="venice-shaped")
+    ap.add_argument("--cpu-iters", type=int, default=30, help="LM iterations of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        # torch.distributed is the launcher-side plumbing (rendezvous, barrier, max over ranks);
+        # the data-path collective is RCCL inside the library, on the library's stream.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    prob, data_kind = load_workload(args.workload, rank, world)
+    h = psba_amd.Psba(local_rank)
+    if world > 1:
+        uid = [psba_amd.Psba.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(world, rank, uid[0])
+    h.upload_problem(prob)
+    cams0, pts0 = np.array(prob["cams"], copy=True), np.array(prob["pts"], copy=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # warmup: W untimed LM iterations, then back to the initial parameters
+    if args.warmup > 0:
+        h.levmar(max_iter=args.warmup, tr_handoff=False, log_cap=0)
+        h.set_params(cams0, pts0)
+    h.profile_enable(True)
+    h.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    res, _ = h.levmar(max_iter=args.steps, tr_handoff=False, log_cap=0)  # returns synchronised
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    n_obs_total = prob["nO"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        n = torch.tensor([prob["nO"], prob["nP"]], dtype=torch.int64)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        n_obs_total, n_pts_total = int(n[0]), int(n[1])
+    else:
+        n_pts_total = prob["nP"]
+    steps_done = res.iters
+    kern = {}
+    for k, name in enumerate(capi.KERNEL_NAMES):
+        ms, n = h.profile_get(k)
+        if n:
+            kern[name] = {"avg_us": 1e3 * ms / n, "launches": n}
+    h.profile_enable(False)
+
+    out = None
+    if rank == 0:
+        sch_bytes = h.algorithmic_bytes(capi.K_SCHUR)
+        sch_us = kern["schur"]["avg_us"]
+        achieved = sch_bytes / (sch_us * 1e-6) / 1e9
+        out = {
+            "metric": "M-observations/sec through Jacobian+Schur build+solve (ms/LM-iter in ms_per_step)",
+            "value": n_obs_total * steps_done / elapsed / 1e6,
+            "unit": "M-obs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": data_kind,
+            "config": {"workload": args.workload + ("" if world == 1 else f" x{world} shards"),
+                       "n_cams": int(prob["nC"]), "n_pts": n_pts_total, "n_obs": n_obs_total,
+                       "lm": "levmar, TR hand-off disabled", "parallelism": f"points sharded x{world}"},
+            "steps_completed": steps_done, "damping_tries": res.tries, "lm_flag": res.flag,
+            "init_cost": res.init_err, "final_cost": res.final_err,
+            "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
+            "roofline": {"kernel": "schur assemble (W/Y/S/ea)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_lib import Oracle  # the checker, timed as the CPU baseline ("port")
+            o = Oracle(prob)
+            tc = time.perf_counter()
+            ores, _ = o.levmar(max_iter=args.cpu_iters, tr_handoff=False, log_cap=0)
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {
+                "value": prob["nO"] * ores.iters / tc / 1e6, "unit": "M-obs/s", "cores": 1, "kind": "port",
+                "ms_per_lm_iter": 1e3 * tc / max(ores.iters, 1),
+                "sample": f"{ores.iters} LM iterations of the same {args.workload} problem "
+                          f"({prob['nO']} observations), oracle/psba_oracle.c single thread",
+                "final_cost": ores.final_err,
+            }
+            # same inputs, same iteration count => costs must agree when both ran the same steps
+            if ores.iters == steps_done:
+                out["cost_rel_diff_vs_cpu"] = abs(res.final_err - ores.final_err) / ores.final_err
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

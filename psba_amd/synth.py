@@ -38,9 +38,14 @@ def project(K, q0, cams, M):
 
 
 def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, noise_px=1.0,
-                 cam_sigma=1e-3, pt_sigma=1e-2, focal=1000.0):
-    """Cameras on a circle of radius 10 looking at the origin; points in the unit ball."""
-    rng = np.random.default_rng(seed)
+                 cam_sigma=1e-3, pt_sigma=1e-2, focal=1000.0, shard=0):
+    """Cameras on a circle of radius 10 looking at the origin; points in the unit ball.
+
+    `shard` selects an independent stream for the points and observations while the cameras
+    (and their initial perturbation) depend on `seed` only: shards 0..N-1 of one seed are the
+    per-rank pieces of one N-times-larger problem over the same cameras."""
+    rng = np.random.default_rng([seed, 1 + shard])
+    rng_cam = np.random.default_rng([seed, 0])
     max_track = n_cams if max_track is None else min(max_track, n_cams)
     # cameras: centre c_j on a circle, rotation taking the world z-axis towards the origin
     ang = 2 * np.pi * np.arange(n_cams) / n_cams
@@ -92,18 +97,18 @@ def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, n
     xy, depth = project(K[jidx], q[jidx], true_cams[jidx], M[iidx])
     assert np.all(depth > 0)
     impts = xy + rng.normal(0, noise_px, xy.shape)
-    cams0 = true_cams + np.concatenate([rng.normal(0, cam_sigma, (n_cams, 3)),
-                                        rng.normal(0, cam_sigma, (n_cams, 3))], 1)
+    cams0 = true_cams + np.concatenate([rng_cam.normal(0, cam_sigma, (n_cams, 3)),
+                                        rng_cam.normal(0, cam_sigma, (n_cams, 3))], 1)
     pts0 = M + rng.normal(0, pt_sigma, M.shape)
     return Problem(K=K, initrot=q, cams=cams0, pts=pts0, impts=impts, iidx=iidx, jidx=jidx,
                    nC=n_cams, nP=n_pts, nO=int(iidx.size))
 
 
-def venice_shaped(n_pts=64053, seed=0x5BA0 + 4):
+def venice_shaped(n_pts=64053, seed=0x5BA0 + 4, shard=0):
     """Venice-52-64053-shaped: 52 cameras, 64053 points, mean track 5.42."""
-    return make_problem(52, n_pts, 5.42, seed)
+    return make_problem(52, n_pts, 5.42, seed, shard=shard)
 
 
-def trafalgar50_shaped(seed=0x5BA0 + 3):
+def trafalgar50_shaped(seed=0x5BA0 + 3, shard=0):
     """Trafalgar-50-20431-shaped: 50 cameras, 20431 points, mean track 3.62."""
-    return make_problem(50, 20431, 3.62, seed)
+    return make_problem(50, 20431, 3.62, seed, shard=shard)
