@@ -203,7 +203,8 @@ void psba_free_problem(psba_problem *p);
 #define PSBA_K_BACKSUB 3
 #define PSBA_K_RESIDUAL 4
 #define PSBA_K_ALLREDUCE 5
-#define PSBA_K_COUNT 6
+#define PSBA_K_SCHUR_REDUCE 6 /* slab sum + U + mu I + mirror that finishes S after PSBA_K_SCHUR */
+#define PSBA_K_COUNT 7
 int psba_profile_enable(psba_handle h, int on);
 int psba_profile_reset(psba_handle h);
 /* total_ms and launch count per kernel class since the last reset (synchronises) */

@@ -17,8 +17,8 @@ PSBA_OK, PSBA_NOT_SPD, PSBA_SINGULAR_V = 0, 1, 2
 PARAMS_CUR, PARAMS_NEW = 0, 1
 ITER_TURN_TO_LM, ITER_TURN_TO_TR, ITER_CONTINUE, ITER_ERR = 1, 2, 3, 4
 ITER_DP_NO_CHANGE, ITER_ERR_SMALL_ENOUGH, ITER_PASS = 5, 6, 7
-K_LINEARIZE, K_SCHUR, K_CHOLESKY, K_BACKSUB, K_RESIDUAL, K_ALLREDUCE = range(6)
-KERNEL_NAMES = ["linearize", "schur", "cholesky", "backsub", "residual", "allreduce"]
+K_LINEARIZE, K_SCHUR, K_CHOLESKY, K_BACKSUB, K_RESIDUAL, K_ALLREDUCE, K_SCHUR_REDUCE = range(7)
+KERNEL_NAMES = ["linearize", "schur", "cholesky", "backsub", "residual", "allreduce", "schur_reduce"]
 
 _h = C.c_void_p
 _dp = C.POINTER(C.c_double)

@@ -12,6 +12,8 @@
 // block triangle of S (cameras ascend inside a point).  k_schur_finalize adds U + mu I and
 // g_a and mirrors the upper block triangle.
 #include "camera_model.h"
+#include <cstdlib>
+
 #include "psba_internal.h"
 
 namespace psba {
@@ -111,6 +113,161 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
     if (sEa[t] != 0.0) atomicAdd(&p.ea[t], sEa[t]);
 }
 
+// v2: the lower block triangle of S is split into camera-row groups whose packed size fits
+// in LDS; workgroup (g, chunk) streams the tiles of its point chunk and accumulates the
+// products whose row camera lies in group g with LDS atomics (ds_add_f64), then writes its
+// partition once, as plain stores, into the chunk's slab.  k_schur_reduce sums the slabs in
+// chunk order.  The G workgroups of one chunk are mapped to the same XCD (blockIdx % 8) so
+// that the re-reads of the chunk's W blocks are L2 hits.
+struct SchurLdsArgs {
+  const double *W, *PV;
+  const int *iidx, *jidx, *ptr, *tile_pt, *chunk_tile;
+  double *slab;
+  int *status;
+  double *dbg_Y, *dbg_Vinv;
+  double mu;
+  int nC, nA, nGroups, nChunks;
+  unsigned long long slabStride;  // packedN + nA
+  unsigned long long packedN;
+  int glo[MAX_GROUPS + 1];
+};
+
+__device__ __forceinline__ int tri(int j) { return j * (j + 1) / 2; }
+
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_schur_lds(SchurLdsArgs p) {
+  __shared__ double sW[TILE_OBS * 18];
+  __shared__ double sVi[TILE_PTS][9];  // V^-1 sym6 | g_b
+  __shared__ int sJ[TILE_OBS];
+  extern __shared__ double sPart[];    // packed rows [lo,hi) of the block triangle, then e_a rows
+  const int tid = threadIdx.x;
+  int g, chunk;
+  if ((p.nChunks & 7) == 0) {
+    chunk = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * p.nGroups));
+    g = (blockIdx.x >> 3) % p.nGroups;
+  } else {
+    g = blockIdx.x % p.nGroups;
+    chunk = blockIdx.x / p.nGroups;
+  }
+  const int lo = p.glo[g], hi = p.glo[g + 1];
+  const int Tlo = tri(lo);
+  const int nPart = 36 * (tri(hi) - Tlo);
+  double *sEa = sPart + nPart;
+  const int nEa = 6 * (hi - lo);
+  for (int t = tid; t < nPart + nEa; t += TILE_OBS) sPart[t] = 0.0;
+
+  const int t0 = p.chunk_tile[chunk], t1 = p.chunk_tile[chunk + 1];
+  for (int tile = t0; tile < t1; tile++) {
+    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
+    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+    const int nobs = o1 - o0;
+    __syncthreads();
+    {
+      const double2 *src = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)o0);
+      double2 *dst = reinterpret_cast<double2 *>(sW);
+      for (int t = tid; t < nobs * 9; t += TILE_OBS) dst[t] = src[t];
+    }
+    if (tid < nobs) sJ[tid] = p.jidx[o0 + tid];
+    if (p0 + tid < p1) {
+      const double *pv = p.PV + 9 * (size_t)(p0 + tid);
+      double v[6], vi[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = pv[k];
+      v[0] += p.mu;
+      v[3] += p.mu;
+      v[5] += p.mu;
+      const bool sing = sym3_inverse(v, vi);
+      if (sing && g == 0) atomicOr(&p.status[0], 1);
+#pragma unroll
+      for (int k = 0; k < 6; k++) sVi[tid][k] = vi[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) sVi[tid][6 + k] = pv[6 + k];
+      if (DUMP && g == 0) {
+        double *o = p.dbg_Vinv + 9 * (size_t)(p0 + tid);
+        o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
+        o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
+        o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
+      }
+    }
+    __syncthreads();
+    if (tid < nobs) {
+      const int ja = sJ[tid];
+      if (ja >= lo && ja < hi) {
+        const int a = o0 + tid;
+        const int i = p.iidx[a];
+        const double *vi = sVi[i - p0];
+        const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+        const double g0 = vi[6], g1 = vi[7], g2 = vi[8];
+        double Y[18];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const double w0 = sW[18 * tid + 3 * r], w1 = sW[18 * tid + 3 * r + 1],
+                       w2 = sW[18 * tid + 3 * r + 2];
+          Y[3 * r] = w0 * i00 + w1 * i01 + w2 * i02;
+          Y[3 * r + 1] = w0 * i01 + w1 * i11 + w2 * i12;
+          Y[3 * r + 2] = w0 * i02 + w1 * i12 + w2 * i22;
+          atomicAdd(&sEa[6 * (ja - lo) + r],
+                    -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
+        }
+        if (DUMP) {
+#pragma unroll
+          for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
+        }
+        const int b0 = p.ptr[i] - o0;
+        double *rowbase = sPart + 36 * (tri(ja) - Tlo);
+        for (int b = b0; b <= tid; b++) {
+          double *blk = rowbase + 36 * sJ[b];
+          const double *wb = sW + 18 * b;
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+              atomicAdd(&blk[6 * r + c], -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double *slab = p.slab + (size_t)chunk * p.slabStride;
+  for (int t = tid; t < nPart; t += TILE_OBS) slab[36 * (size_t)Tlo + t] = sPart[t];
+  for (int t = tid; t < nEa; t += TILE_OBS) slab[p.packedN + 6 * lo + t] = sEa[t];
+}
+
+// sums the chunk slabs (chunk order), adds blockdiag(U) + mu_add I and g_a, and writes the
+// full row-major S (both block triangles) and e_a.
+__global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nChunks,
+                                                      unsigned long long slabStride,
+                                                      unsigned long long packedN, const double *U,
+                                                      const double *ga, double mu_add, int nA,
+                                                      double *S, double *ea) {
+  const unsigned long long total = packedN + nA;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (unsigned long long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int c = 0; c < nChunks; c++) acc += slab[(size_t)c * slabStride + e];
+    if (e >= packedN) {
+      const int t = (int)(e - packedN);
+      ea[t] = ga[t] + acc;
+      continue;
+    }
+    const int blk = (int)(e / 36), rc = (int)(e % 36);
+    int j = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while (tri(j + 1) <= blk) j++;
+    while (tri(j) > blk) j--;
+    const int jb = blk - tri(j);
+    const int r = rc / 6, c = rc % 6;
+    if (j == jb) {
+      acc += U[36 * j + rc];
+      if (r == c) acc += mu_add;
+    } else {
+      S[(size_t)(6 * jb + c) * nA + 6 * j + r] = acc;
+    }
+    S[(size_t)(6 * j + r) * nA + 6 * jb + c] = acc;
+  }
+}
+
 // S += blockdiag(U) + mu_add I on the lower block triangle, mirror to the upper block
 // triangle, ea += g_a.  mu_add is mu on rank 0 and 0 elsewhere so that the all-reduce of
 // the per-rank contributions adds mu exactly once.
@@ -133,7 +290,72 @@ __global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, c
     ea[t] += ga[t];
 }
 
+static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
+  const Dims &d = h->d;
+  SchurLdsArgs a;
+  a.W = h->W;
+  a.PV = h->PV;
+  a.iidx = h->iidx;
+  a.jidx = h->jidx;
+  a.ptr = h->ptr;
+  a.tile_pt = h->tile_pt;
+  a.chunk_tile = h->chunk_tile;
+  a.slab = h->slab;
+  a.status = h->status;
+  a.dbg_Y = h->dbg_Y;
+  a.dbg_Vinv = h->dbg_Vinv;
+  a.mu = mu;
+  a.nC = d.nC;
+  a.nA = d.nA;
+  a.nGroups = h->nGroups;
+  a.nChunks = h->nChunks;
+  a.packedN = h->packedN;
+  a.slabStride = h->packedN + d.nA;
+  size_t worst = 0;
+  for (int g = 0; g <= h->nGroups; g++) a.glo[g] = h->glo[g];
+  for (int g = 0; g < h->nGroups; g++) {
+    const size_t lo = h->glo[g], hi = h->glo[g + 1];
+    const size_t n = 36 * (hi * (hi + 1) / 2 - lo * (lo + 1) / 2) + 6 * (hi - lo);
+    if (n > worst) worst = n;
+  }
+  const size_t lds = sizeof(double) * worst;
+  PSBA_HIP(h, hipMemsetAsync(h->status, 0, sizeof(int) * 4, h->stream));
+  const int grid = h->nGroups * h->nChunks;
+  const double mu_add = h->rank == 0 ? mu : 0.0;
+  const size_t total = h->packedN + d.nA;
+  int rgrid = (int)((total + 255) / 256);
+  {
+    ProfScope ps(h, PSBA_K_SCHUR);
+    if (dump)
+      hipLaunchKernelGGL(k_schur_lds<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_schur_lds<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+  }
+  {
+    ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
+    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, h->slab, h->nChunks,
+                       a.slabStride, a.packedN, h->U, h->ga, mu_add, d.nA, h->red,
+                       h->red + (size_t)d.nA * d.nA);
+  }
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+static bool g_lds_attr_set = false;
+
 int launch_schur(psba_ctx *h, double mu, bool dump) {
+  if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
+    if (!g_lds_attr_set) {
+      // allow the full 160 KiB of LDS for the partition
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 47104));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 47104));
+      g_lds_attr_set = true;
+    }
+    return launch_schur_lds(h, mu, dump);
+  }
+
   const Dims &d = h->d;
   SchurArgs a;
   a.W = h->W;

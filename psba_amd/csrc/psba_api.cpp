@@ -97,6 +97,8 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->ga);
   dev_free(h->campart);
   dev_free(h->red);
+  dev_free(h->chunk_tile);
+  dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->dbg_ex);
   dev_free(h->dbg_JA);
@@ -203,7 +205,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     int p0 = 0;
     while (p0 < n3Dpts) {
       int p1 = p0;
-      while (p1 < n3Dpts && (ptr[(size_t)p1 + 1] - ptr[p0]) <= TILE_OBS && (p1 - p0) < TILE_OBS) p1++;
+      while (p1 < n3Dpts && (ptr[(size_t)p1 + 1] - ptr[p0]) <= TILE_OBS && (p1 - p0) < TILE_PTS) p1++;
       tile_pt.push_back(p1);
       p0 = p1;
     }
@@ -247,6 +249,52 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
   TRY(dev_alloc(h, &h->red, (size_t)d.nA * d.nA + d.nA));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
+  // ---- K2 decomposition: S's lower block triangle is split into camera-row groups whose
+  // packed size fits the LDS budget; every (group, point chunk) pair is one workgroup ----
+  {
+    const size_t total_blocks = (size_t)nCams * (nCams + 1) / 2;
+    h->packedN = 36 * total_blocks;
+    const size_t budget_blocks = (size_t)(163840 - 47104 - 512 - 48 * 64) / (36 * sizeof(double));
+    h->nGroups = 0;
+    for (int G = 1; G <= MAX_GROUPS; G++) {
+      // equal-area split of the triangle into G row groups
+      std::vector<int> lo(1, 0);
+      for (int g = 1; g < G; g++) {
+        const double target = (double)total_blocks * g / G;
+        int j = lo.back();
+        while (j < nCams && (double)j * (j + 1) / 2 < target) j++;
+        if (j <= lo.back()) j = lo.back() + 1;
+        if (j > nCams) j = nCams;
+        lo.push_back(j);
+      }
+      lo.push_back(nCams);
+      size_t worst = 0;
+      bool ok = true;
+      for (int g = 0; g < G; g++) {
+        if (lo[g + 1] <= lo[g]) { ok = false; break; }
+        const size_t blk = (size_t)lo[g + 1] * (lo[g + 1] + 1) / 2 - (size_t)lo[g] * (lo[g] + 1) / 2;
+        // partition + its e_a rows must fit
+        if (blk + (size_t)(lo[g + 1] - lo[g]) > worst) worst = blk + (size_t)(lo[g + 1] - lo[g]);
+      }
+      if (ok && worst <= budget_blocks) {
+        h->nGroups = G;
+        for (int g = 0; g <= G; g++) h->glo[g] = lo[g];
+        break;
+      }
+    }
+    if (h->nGroups) {
+      int nChunks = 256 / h->nGroups;
+      if (nChunks < 1) nChunks = 1;
+      if (nChunks > d.nTiles) nChunks = d.nTiles;
+      if (nChunks >= 8) nChunks -= nChunks % 8;
+      h->nChunks = nChunks;
+      std::vector<int> ct((size_t)nChunks + 1);
+      for (int c = 0; c <= nChunks; c++) ct[c] = (int)((long long)d.nTiles * c / nChunks);
+      TRY(dev_alloc(h, &h->chunk_tile, ct.size()));
+      TRY(dev_alloc(h, &h->slab, (size_t)nChunks * (h->packedN + d.nA)));
+      PSBA_HIP(h, hipMemcpy(h->chunk_tile, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice));
+    }
+  }
   auto H2D = [&](void *dst, const void *src, size_t bytes) {
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
   };

@@ -13,6 +13,8 @@
 namespace psba {
 
 constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= threads per workgroup)
+constexpr int TILE_PTS = 128;   // points per tile (bounds the per-point LDS rows)
+constexpr int MAX_GROUPS = 32;  // camera-row groups of the LDS-resident S partition (K2)
 constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
 constexpr int NSCAL = 16;       // device scalar block (doubles)
 
@@ -61,6 +63,12 @@ struct psba_ctx {
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
   int nPart = 0;
   double *red = nullptr;        // [nA*nA + nA]  S | ea, the all-reduce buffer (S_buffer, eab_buffer)
+  // K2 (schur) decomposition: camera-row groups x point chunks, one workgroup each
+  int nGroups = 0, nChunks = 0; // nGroups == 0: fall back to global atomics
+  int glo[psba::MAX_GROUPS + 1] = {0};  // group g owns camera rows [glo[g], glo[g+1])
+  int *chunk_tile = nullptr;    // [nChunks+1] first tile of each chunk
+  double *slab = nullptr;       // [nChunks][packedN + nA] per-chunk partial -sum(Y W^T) | -sum(Y g_b)
+  size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
   double *scal = nullptr;       // [NSCAL]
   int *status = nullptr;        // [4]  [0]=singular V, [1]=not SPD
