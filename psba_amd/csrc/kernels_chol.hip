@@ -4,158 +4,324 @@
 // Replaces SPDinv = cholesky -> trigMat_inv -> trigMat_mul (+ kern_fill_rest) and matVec_mul
 // (reference PSBA/cl_spdinv.cpp:18-204, CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19,
 // CL_files/matVec_mul.cl:7-18): the reference chains ~nA device-enqueued launches of 3x3
-// blocks; here one workgroup runs a right-looking blocked factorisation with the forward
-// solve folded in (ea is carried as an extra row of the matrix) and a blocked backward
-// solve.  A non-positive or non-finite pivot sets status[1] (the reference's ret = 1.0,
-// SPD_inv.cl:35-38,66).
+// blocks and then multiplies by an explicit inverse.  A non-positive or non-finite pivot
+// sets status[1] (the reference's ret = 1.0, SPD_inv.cl:35-38,66).
 //
-// v1: one workgroup, vector fp64 (no MFMA yet), n <= CHOL_MAX_N.
+// Data: the reduce buffer is the padded matrix Lw[(n32+16)][n32] (row-major, n32 = n rounded
+// up to 32): rows < n hold S, rows n..n32-1 identity padding, row n32 holds e_a, the rest
+// zeros -- so every load is branch-free and e_a rides along as one more row (the forward
+// solve L y = e_a comes for free).
+//
+// One workgroup of 8 waves, left-looking by block columns of 32:
+//   A  the 32 rows of the block column's own L are staged in LDS (the B operand); every wave
+//      owns row tiles (16 rows) and applies all previous block columns with
+//      v_mfma_f64_16x16x4_f64 (C -= L_rows L_cols^T), accumulators in registers, A operands
+//      prefetched from the L2-resident matrix four k-steps ahead;
+//   B  the 32x32 diagonal block is factored by one wave, rows in registers, columns passed
+//      between lanes with v_readlane;
+//   C  the rows below are finished by forward substitution against the block, one thread
+//      per row.
+// The backward solve L^T x = y is blocked the same way (substitution in one wave per block,
+// then a rank-32 update of the remaining right-hand side by all threads).
 #include "psba_internal.h"
 
 namespace psba {
 
-constexpr int NB = 16;
-constexpr int CHOL_THREADS = 1024;
-constexpr int CHOL_MAX_N = 1024;
+constexpr int CB = 16;  // block column width (one MFMA column tile)
+constexpr int CT = CB / 16;
+constexpr int CHOL_THREADS = 512;
+constexpr int CHOL_WAVES = CHOL_THREADS / 64;
+constexpr int CHOL_KU = 4;  // k-steps (of 4) per prefetch group: 16 columns, divides every j
 
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *S, double *ea, double *x,
-                                                             int n, int *status) {
-  __shared__ double sD[NB][NB + 1];
-  __shared__ double sX[NB];
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double dcb __attribute__((ext_vector_type(CB)));  // SSA vector: never demoted to scratch
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// MAXT = row tiles a wave may own in one block column: ceil((n32/16 + 1) / CHOL_WAVES)
+template <int MAXT>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double *x,
+                                                             double *linv_store, int n, int n32,
+                                                             int *status, long long *tim) {
+  __shared__ double sD[CB][CB + 1];              // diagonal block, then its Cholesky factor
+  __shared__ double sInvD[CB];                   // 1 / diag of the factor
+  __shared__ double sX[CB];
+  __shared__ double sCol[CB];
   __shared__ int sFail;
-  extern __shared__ double sP[];  // [(n+1)][NB+1] panel below the diagonal block (+ ea row)
-  const int tid = threadIdx.x;
+  extern __shared__ double sB[];  // [32][ldb] rows j..j+31 of L, columns < j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ld = n32;
+  const int ldb = n32 + 1;
+  const int nTiles = n32 / 16 + 1;  // row tiles incl. the e_a tile
   if (tid == 0) sFail = 0;
+  // Pull the whole matrix into this XCD's L2 first, with as many lines in flight as the
+  // workgroup can keep: the producer kernel ran on all eight XCDs, so every first touch
+  // would otherwise be a dependent ~2 us miss in the middle of the factorisation.
+  {
+    const size_t nLines = ((size_t)(n32 + 1) * n32 * sizeof(double) + 127) / 128;
+    const float *base = reinterpret_cast<const float *>(Lw);
+    float warm = 0.f;
+    for (size_t l0 = 0; l0 < nLines; l0 += 8 * CHOL_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const size_t l = l0 + (size_t)u * CHOL_THREADS + tid;
+        v[u] = (l < nLines) ? base[l * 32] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) warm += v[u];
+    }
+    if (warm == 1.2345e-30f) sFail = 2;  // keeps the loads alive; never true in practice
+  }
   __syncthreads();
+  long long tA = 0, tB = 0, tC = 0, tBack = 0, t0 = 0, tF = 0, tS = 0;
+#define STAMP() (tim ? (long long)__builtin_amdgcn_s_memtime() : 0)
 
-  for (int jb = 0; jb < n; jb += NB) {
-    const int nb = (n - jb) < NB ? (n - jb) : NB;
-    // 1. diagonal block -> LDS
-    if (tid < NB * NB) {
-      const int r = tid / NB, c = tid % NB;
-      if (r < nb && c <= r) sD[r][c] = S[(size_t)(jb + r) * n + jb + c];
+  for (int j = 0; j < n32; j += CB) {
+    const int firstTile = j / 16;  // j is a multiple of CB
+    t0 = STAMP();
+    // ---- phase A: acc = C - L[rows, 0:j] L[j:j+32, 0:j]^T ---------------------------------
+    for (int r = wave; r < CB; r += CHOL_WAVES) {
+      const double *src = Lw + (size_t)(j + r) * ld;
+      for (int c = lane; c < j; c += 64) sB[r * ldb + c] = src[c];
+    }
+    d4 acc[MAXT][CT];
+    const double *arow[MAXT];
+    int ntile = 0;
+#pragma unroll
+    for (int q = 0; q < MAXT; q++) {
+      const int T = firstTile + wave + q * CHOL_WAVES;
+      const int Tc = T < nTiles ? T : nTiles - 1;  // clamp: harmless duplicate work, never stored
+      if (T < nTiles) ntile = q + 1;
+      arow[q] = Lw + (size_t)(16 * Tc + li) * ld + lk;
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          acc[q][ct][r] = Lw[(size_t)(16 * Tc + lk + 4 * r) * ld + j + 16 * ct + li];
     }
     __syncthreads();
-    // 2. factor it in one wave: lane = row
-    if (tid < 64) {
-      const int r = tid;
-      for (int j = 0; j < nb; j++) {
-        const double d = sD[j][j];
-        const double l = sqrt(d);
-        if (!(d > 0.0) || !isfinite(l)) {
-          if (r == 0) sFail = 1;
+    { long long t1 = STAMP(); tS += t1 - t0; }
+    {
+      double an[MAXT][CHOL_KU];
+#pragma unroll
+      for (int q = 0; q < MAXT; q++)
+#pragma unroll
+        for (int u = 0; u < CHOL_KU; u++) an[q][u] = (j > 0) ? arow[q][4 * u] : 0.0;
+      for (int k0 = 0; k0 < j; k0 += 4 * CHOL_KU) {
+        double ac[MAXT][CHOL_KU];
+#pragma unroll
+        for (int q = 0; q < MAXT; q++)
+#pragma unroll
+          for (int u = 0; u < CHOL_KU; u++) ac[q][u] = an[q][u];
+        if (k0 + 4 * CHOL_KU < j) {
+#pragma unroll
+          for (int q = 0; q < MAXT; q++)
+            if (q < ntile) {
+#pragma unroll
+              for (int u = 0; u < CHOL_KU; u++) an[q][u] = arow[q][k0 + 4 * CHOL_KU + 4 * u];
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (r == j) sD[j][j] = l;
-        if (r > j && r < nb) sD[r][j] = sD[r][j] / l;
-        __builtin_amdgcn_wave_barrier();
-        if (r > j && r < nb) {
-          const double lrj = sD[r][j];
-          for (int c = j + 1; c <= r; c++) sD[r][c] -= lrj * sD[c][j];
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    __syncthreads();
-    if (sFail) break;
-    if (tid < NB * NB) {
-      const int r = tid / NB, c = tid % NB;
-      if (r < nb && c <= r) S[(size_t)(jb + r) * n + jb + c] = sD[r][c];
-    }
-    // 3. panel solve: rows below the block and the ea row; one thread per row
-    const int r0 = jb + nb;          // first trailing row / column
-    const int m = n - r0 + 1;        // trailing rows including the ea row
-    for (int t = tid; t < m; t += CHOL_THREADS) {
-      const int R = r0 + t;
-      double *row = (R < n) ? (S + (size_t)R * n + jb) : (ea + jb);
-      double a[NB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) a[c] = (c < nb) ? row[c] : 0.0;
+        for (int u = 0; u < CHOL_KU; u++) {
+          double bq[CT];
 #pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < nb) {
-          double v = a[c];
+          for (int ct = 0; ct < CT; ct++) bq[ct] = sB[(16 * ct + li) * ldb + k0 + 4 * u + lk];
 #pragma unroll
-          for (int k = 0; k < NB; k++)
-            if (k < c) v -= a[k] * sD[c][k];
-          a[c] = v / sD[c][c];
+          for (int q = 0; q < MAXT; q++) {
+            if (q < ntile) {  // wave-uniform: late block columns have fewer row tiles than slots
+#pragma unroll
+              for (int ct = 0; ct < CT; ct++)
+                acc[q][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q][u], bq[ct], acc[q][ct], 0, 0, 0);
+            }
+          }
         }
       }
+    }
+    {
+      long long t1 = STAMP();
+      tA += t1 - t0;
+      t0 = t1;
+    }
+    // ---- phase B: diagonal block -> LDS, factor + invert in one wave ---------------------
+    // the diagonal block lives in row tiles firstTile, firstTile+1 = waves 0 and 1, q = 0.
+    // The other updated tiles go back to the matrix in place (phase C re-reads them in the
+    // A-operand layout), so no accumulator stays live across the serial phase.
 #pragma unroll
-      for (int c = 0; c < NB; c++) {
-        if (c < nb) row[c] = a[c];
-        sP[t * (NB + 1) + c] = a[c];
+    for (int q = 0; q < MAXT; q++) {
+      const int T = firstTile + wave + q * CHOL_WAVES;
+      if (q < ntile && T >= firstTile + CT) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 * ct + li] = acc[q][ct][r];
+      }
+    }
+    if (wave < CT) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sD[16 * wave + lk + 4 * r][16 * ct + li] = acc[0][ct][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane r < 32 keeps row r of the block in registers (an SSA vector); the pivot and the
+      // finished column goes through LDS and is read back with uniform addresses (broadcast).
+      const int r = lane & (CB - 1);
+      dcb a;
+#pragma unroll
+      for (int c = 0; c < CB; c++) a[c] = sD[r][c];
+      bool bad = false;
+#pragma clang loop unroll(full)
+      for (int c = 0; c < CB; c++) {
+        const double d = readlane_f64(a[c], c);
+        bad |= !(d > 0.0);
+        double y = __builtin_amdgcn_rsq(d);            // ~ 1/sqrt(d)
+        y = y * (1.5 - 0.5 * d * y * y);               // two Newton steps: full fp64
+        y = y * (1.5 - 0.5 * d * y * y);
+        const double l = (r == c) ? d * y : a[c] * y;  // L[c][c] = sqrt(d), L[r][c] = a/sqrt(d)
+        a[c] = l;
+        if (lane == c) sInvD[c] = y;                   // 1 / L[c][c]
+        if (c + 1 < CB) {
+          sCol[r] = l;                                 // finished column -> LDS, read back uniformly
+          __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(full)
+          for (int cc = c + 1; cc < CB; cc++) a[cc] -= l * sCol[cc];
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (lane < CB) {
+#pragma unroll
+        for (int c = 0; c < CB; c++) sD[r][c] = (c <= r) ? a[c] : 0.0;
+        if (bad || !isfinite(a[r])) sFail = 1;
+      }
+      {
+        long long t1 = STAMP();
+        tF += t1 - t0;
       }
     }
     __syncthreads();
-    // 4. trailing update  A[R][C] -= P[R] . P[C]  for r0 <= C <= R (lower), R up to the ea row
-    const int mc = m - 1;  // trailing columns
-    if (mc > 0) {
-      const int total = m * mc;
-      for (int t = tid; t < total; t += CHOL_THREADS) {
-        const int rr = t / mc, cc = t % mc;
-        if (cc > rr) continue;
-        double acc = 0.0;
+    {
+      long long t1 = STAMP();
+      tB += t1 - t0;
+      t0 = t1;
+    }
+    if (sFail == 1) break;
+    for (int t = tid; t < CB * CB; t += CHOL_THREADS) {
+      const int r = t / CB, c = t % CB;
+      Lw[(size_t)(j + r) * ld + j + c] = sD[r][c];
+    }
+    // ---- phase C: X L_dd^T = C for the rows below the diagonal block, one thread per row:
+    // forward substitution with the row in registers, L_dd from LDS (uniform addresses
+    // broadcast).  The e_a row is one of the rows.
+    // (16 nTiles <= CHOL_THREADS + CB is checked at launch: one row per thread, no loop, so the
+    // block's entries are not hoisted into registers all at once)
+    if (const int R = j + CB + tid; R < 16 * nTiles) {
+      double *row = Lw + (size_t)R * ld + j;
+      dcb xr;
 #pragma unroll
-        for (int k = 0; k < NB; k++) acc += sP[rr * (NB + 1) + k] * sP[cc * (NB + 1) + k];
-        double *dst = (r0 + rr < n) ? (S + (size_t)(r0 + rr) * n + r0 + cc) : (ea + r0 + cc);
-        *dst -= acc;
+      for (int c = 0; c < CB; c++) xr[c] = row[c];
+#pragma clang loop unroll(full)
+      for (int c = 0; c < CB; c++) {
+        double v = xr[c];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < c; k++) v -= xr[k] * sD[c][k];
+        xr[c] = v * sInvD[c];
       }
+#pragma unroll
+      for (int c = 0; c < CB; c++) row[c] = xr[c];
     }
     __syncthreads();
+    {
+      long long t1 = STAMP();
+      tC += t1 - t0;
+      t0 = t1;
+    }
   }
 
-  if (sFail) {
+  if (sFail == 1) {
     if (tid == 0) atomicOr(&status[1], 1);
     for (int t = tid; t < n; t += CHOL_THREADS) x[t] = 0.0;
     return;
   }
 
-  // backward solve  L^T x = y  (y is in ea), blocked from the last panel up
-  const int last = ((n - 1) / NB) * NB;
-  for (int jb = last; jb >= 0; jb -= NB) {
-    const int nb = (n - jb) < NB ? (n - jb) : NB;
-    if (tid < NB * NB) {
-      const int r = tid / NB, c = tid % NB;
-      if (r < nb && c <= r) sD[r][c] = S[(size_t)(jb + r) * n + jb + c];
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int c = tid;
-      double y = (c < nb) ? ea[jb + c] : 0.0;
-      for (int k = nb - 1; k >= 0; k--) {
-        if (c == k) sX[k] = y / sD[k][k];
-        __builtin_amdgcn_wave_barrier();
-        if (c < k) y -= sD[k][c] * sX[k];
-        __builtin_amdgcn_wave_barrier();
+  // ---- backward solve  L^T x = y  (y = L^-1 e_a now sits in row n32) ----------------------
+  double *y = Lw + (size_t)n32 * ld;
+  for (int j = n32 - CB; j >= 0; j -= CB) {
+    // L_dd^T x_J = y_J by backward substitution in one wave: lane r holds z_r and column r
+    // of L_dd (row k of L_dd is read across lanes, coalesced)
+    if (wave == 0) {
+      const int r = lane & (CB - 1);
+      dcb lcol;
+#pragma unroll
+      for (int k = 0; k < CB; k++) lcol[k] = Lw[(size_t)(j + k) * ld + j + r];  // L_dd[k][r]
+      double z = y[j + r];
+#pragma clang loop unroll(full)
+      for (int k = CB - 1; k >= 0; k--) {
+        const double xk = readlane_f64(z, k) / readlane_f64(lcol[k], k);
+        if (r == k) z = xk;
+        if (r < k) z -= lcol[k] * xk;
+      }
+      if (lane < CB) {
+        sX[r] = z;
+        if (j + r < n) x[j + r] = z;
       }
     }
     __syncthreads();
-    if (tid < nb) x[jb + tid] = sX[tid];
-    for (int c = tid; c < jb; c += CHOL_THREADS) {
+    // y[c] -= sum_r L[j+r][c] x_J[r]  for c < j
+    for (int c = tid; c < j; c += CHOL_THREADS) {
       double acc = 0.0;
-      for (int k = 0; k < nb; k++) acc += S[(size_t)(jb + k) * n + c] * sX[k];
-      ea[c] -= acc;
+#pragma unroll
+      for (int r = 0; r < CB; r++) acc += Lw[(size_t)(j + r) * ld + c] * sX[r];
+      y[c] -= acc;
     }
     __syncthreads();
   }
-  // non-finite solution counts as failure, as in the reference's isfinite checks
+  if (tim && tid == 0) {
+    tBack = STAMP() - t0;
+    tim[0] = tA;
+    tim[1] = tB;
+    tim[2] = tC;
+    tim[3] = tBack;
+    tim[4] = tF;
+    tim[5] = tS;
+  }
   int bad = 0;
   for (int t = tid; t < n; t += CHOL_THREADS)
     if (!isfinite(x[t])) bad = 1;
   if (bad) atomicOr(&status[1], 1);
 }
 
+static bool g_chol_attr = false;
+
 int launch_chol_solve(psba_ctx *h) {
   const Dims &d = h->d;
-  if (d.nA > CHOL_MAX_N)
-    return fail(h, PSBA_E_INVALID, "dense solve supports 6*nCams <= %d for now (got %d)",
-                CHOL_MAX_N, d.nA);
-  const size_t lds = sizeof(double) * (size_t)(d.nA + 1) * (NB + 1);
+  const int n32 = h->n32;
+  const int nTiles = n32 / 16 + 1;
+  const size_t lds = sizeof(double) * CB * (size_t)(n32 + 1);
+  if (nTiles > 4 * CHOL_WAVES || 16 * nTiles > CHOL_THREADS + CB || lds > 163840 - 20 * 1024)
+    return fail(h, PSBA_E_INVALID, "dense solve supports 6*nCams <= 480 for now (got %d)", d.nA);
+  if (!g_chol_attr) {
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_chol_solve<3>, attr, 163840 - 20 * 1024));
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_chol_solve<4>, attr, 163840 - 20 * 1024));
+    g_chol_attr = true;
+  }
   {
     ProfScope ps(h, PSBA_K_CHOLESKY);
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(CHOL_THREADS), lds, h->stream, h->red,
-                       h->red + (size_t)d.nA * d.nA, h->dp, d.nA, h->status);
+    if (nTiles <= 3 * CHOL_WAVES)
+      hipLaunchKernelGGL(k_chol_solve<3>, dim3(1), dim3(CHOL_THREADS), lds, h->stream, h->red, h->dp,
+                         h->chol_ws, d.nA, n32, h->status, h->chol_tim);
+    else
+      hipLaunchKernelGGL(k_chol_solve<4>, dim3(1), dim3(CHOL_THREADS), lds, h->stream, h->red, h->dp,
+                         h->chol_ws, d.nA, n32, h->status, h->chol_tim);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

@@ -2,6 +2,7 @@
 // Takes the place of PSBA/cl_psba.cpp (runtime, buffers, uploads), PSBA/sba_func.cpp (one
 // host wrapper per kernel), PSBA/cl_spdinv.cpp + PSBA/cl_linearalg.cpp (dense solve) and
 // PSBA/misc.cpp:178-217 (index generation) of the reference.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -98,8 +99,11 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->campart);
   dev_free(h->red);
   dev_free(h->chunk_tile);
+  dev_free(h->gobs);
+  dev_free(h->gstart);
   dev_free(h->slab);
   dev_free(h->dp);
+  dev_free(h->chol_ws);
   dev_free(h->dbg_ex);
   dev_free(h->dbg_JA);
   dev_free(h->dbg_JB);
@@ -247,14 +251,21 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
   TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
-  TRY(dev_alloc(h, &h->red, (size_t)d.nA * d.nA + d.nA));
+  h->n32 = (d.nA + 31) / 32 * 32;
+  TRY(dev_alloc(h, &h->red, (size_t)(h->n32 + 16) * h->n32));
+  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
+  TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
+  if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 8));
   // ---- K2 decomposition: S's lower block triangle is split into camera-row groups whose
   // packed size fits the LDS budget; every (group, point chunk) pair is one workgroup ----
   {
     const size_t total_blocks = (size_t)nCams * (nCams + 1) / 2;
     h->packedN = 36 * total_blocks;
-    const size_t budget_blocks = (size_t)(163840 - 47104 - 512 - 48 * 64) / (36 * sizeof(double));
+    // LDS budget of the partition: 37 doubles per 6x6 block (padded stride), 6 per e_a row
+    size_t budget_bytes = 163840 - 1024;
+    if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_bytes = (size_t)atoi(e) * 1024;
+    const size_t budget_doubles = budget_bytes / sizeof(double);
     h->nGroups = 0;
     for (int G = 1; G <= MAX_GROUPS; G++) {
       // equal-area split of the triangle into G row groups
@@ -273,10 +284,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       for (int g = 0; g < G; g++) {
         if (lo[g + 1] <= lo[g]) { ok = false; break; }
         const size_t blk = (size_t)lo[g + 1] * (lo[g + 1] + 1) / 2 - (size_t)lo[g] * (lo[g] + 1) / 2;
-        // partition + its e_a rows must fit
-        if (blk + (size_t)(lo[g + 1] - lo[g]) > worst) worst = blk + (size_t)(lo[g + 1] - lo[g]);
+        const size_t need = 37 * blk + 6 * (size_t)(lo[g + 1] - lo[g]);
+        if (need > worst) worst = need;
       }
-      if (ok && worst <= budget_blocks) {
+      if (ok && worst <= budget_doubles) {
         h->nGroups = G;
         for (int g = 0; g <= G; g++) h->glo[g] = lo[g];
         break;
@@ -290,6 +301,54 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       h->nChunks = nChunks;
       std::vector<int> ct((size_t)nChunks + 1);
       for (int c = 0; c <= nChunks; c++) ct[c] = (int)((long long)d.nTiles * c / nChunks);
+      // compacted observation lists: for every (chunk, group) the observations of the chunk's
+      // points whose camera lies in the group, in observation order
+      {
+        const int G = h->nGroups;
+        std::vector<int> gstart((size_t)nChunks * G + 1, 0), gobs((size_t)n2Dprojs);
+        std::vector<int> grp_of_cam((size_t)nCams);
+        for (int g = 0; g < G; g++)
+          for (int j = h->glo[g]; j < h->glo[g + 1]; j++) grp_of_cam[j] = g;
+        for (int c = 0; c < nChunks; c++) {
+          const int o0 = ptr[tile_pt[ct[c]]], o1 = ptr[tile_pt[ct[c + 1]]];
+          for (int a = o0; a < o1; a++) gstart[(size_t)c * G + grp_of_cam[jidx[a]] + 1]++;
+        }
+        for (size_t k = 0; k < (size_t)nChunks * G; k++) gstart[k + 1] += gstart[k];
+        std::vector<int> fill(gstart.begin(), gstart.end() - 1);
+        for (int c = 0; c < nChunks; c++) {
+          const int o0 = ptr[tile_pt[ct[c]]], o1 = ptr[tile_pt[ct[c + 1]]];
+          for (int a = o0; a < o1; a++) gobs[(size_t)fill[(size_t)c * G + grp_of_cam[jidx[a]]]++] = a;
+        }
+        // inside every (chunk, group) list: sort by trip count of the product loop (position of
+        // the observation inside its point), longest first, so that the 64 lanes of a wave run
+        // the same number of iterations; then deal the blocks of 64 to the 8 waves of a
+        // workgroup forwards and backwards alternately so that the waves' totals even out.
+        {
+          const int WAVES = 8;
+          std::vector<int> tmp;
+          for (size_t k = 0; k < (size_t)nChunks * G; k++) {
+            const int b = gstart[k], e = gstart[k + 1];
+            std::stable_sort(gobs.begin() + b, gobs.begin() + e, [&](int x, int y) {
+              return (x - ptr[iidx[x]]) > (y - ptr[iidx[y]]);
+            });
+            const int nblk = (e - b + 63) / 64;
+            tmp.assign(gobs.begin() + b, gobs.begin() + e);
+            // block q of the sorted list goes to slot (round, wave): forward on even rounds,
+            // backward on odd ones; only whole rounds are permuted (the tail keeps its order)
+            const int fullRounds = nblk / WAVES;
+            for (int r = 1; r < fullRounds; r += 2)
+              for (int w = 0; w < WAVES; w++) {
+                const int src = (r * WAVES + (WAVES - 1 - w)) * 64, dst = (r * WAVES + w) * 64;
+                if (src + 64 <= e - b)
+                  std::copy(tmp.begin() + src, tmp.begin() + src + 64, gobs.begin() + b + dst);
+              }
+          }
+        }
+        TRY(dev_alloc(h, &h->gobs, gobs.size()));
+        TRY(dev_alloc(h, &h->gstart, gstart.size()));
+        PSBA_HIP(h, hipMemcpy(h->gobs, gobs.data(), sizeof(int) * gobs.size(), hipMemcpyHostToDevice));
+        PSBA_HIP(h, hipMemcpy(h->gstart, gstart.data(), sizeof(int) * gstart.size(), hipMemcpyHostToDevice));
+      }
       TRY(dev_alloc(h, &h->chunk_tile, ct.size()));
       TRY(dev_alloc(h, &h->slab, (size_t)nChunks * (h->packedN + d.nA)));
       PSBA_HIP(h, hipMemcpy(h->chunk_tile, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice));
@@ -411,7 +470,7 @@ int psba_schur_reduce(psba_handle h) {
   NEED(h, h->assembled, "psba_schur_assemble first");
   if (!h->comm) return PSBA_OK;
   ProfScope ps(h, PSBA_K_ALLREDUCE);
-  const size_t n = (size_t)h->d.nA * h->d.nA + h->d.nA;
+  const size_t n = (size_t)(h->n32 + 1) * h->n32;  // S rows, padding rows and the ea row
   RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
   return PSBA_OK;
 }
@@ -420,6 +479,13 @@ int psba_schur_solve(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
   TRY(launch_chol_solve(h));
+  if (h->chol_tim) {
+    long long t[8];
+    PSBA_HIP(h, hipMemcpyAsync(t, h->chol_tim, sizeof t, hipMemcpyDeviceToHost, h->stream));
+    PSBA_HIP(h, hipStreamSynchronize(h->stream));
+    fprintf(stderr, "chol cycles: update %lld (staging %lld) diag %lld (factor %lld) trsm %lld backward %lld\n",
+            t[0], t[5], t[1], t[4], t[2], t[3]);
+  }
   h->assembled = false;  // S is overwritten by its factor
   h->solved = true;
   return PSBA_OK;
@@ -489,7 +555,7 @@ static int reassemble_dump(psba_ctx *h) {
   h->assembled = true;
   h->solved = h->backsubbed = false;
   if (h->comm) {
-    const size_t n = (size_t)h->d.nA * h->d.nA + h->d.nA;
+    const size_t n = (size_t)(h->n32 + 1) * h->n32;
     RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
   }
   return PSBA_OK;
@@ -586,7 +652,11 @@ int psba_compute_Yblks(psba_handle h, double *Yblks) {
 int psba_compute_S(psba_handle h, double *S) {
   CHECK_H(h);
   TRY(reassemble_dump(h));
-  return d2h(h, S, h->red, sizeof(double) * (size_t)h->d.nA * h->d.nA);
+  if (!S) return PSBA_OK;
+  PSBA_HIP(h, hipMemcpy2DAsync(S, sizeof(double) * h->d.nA, h->red, sizeof(double) * h->n32,
+                               sizeof(double) * h->d.nA, h->d.nA, hipMemcpyDeviceToHost, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  return PSBA_OK;
 }
 
 int psba_compute_g(psba_handle h, double coeff, double *g) {
@@ -606,7 +676,7 @@ int psba_compute_g(psba_handle h, double coeff, double *g) {
 int psba_compute_ea(psba_handle h, double *ea) {
   CHECK_H(h);
   TRY(reassemble_dump(h));
-  return d2h(h, ea, h->red + (size_t)h->d.nA * h->d.nA, sizeof(double) * (size_t)h->d.nA);
+  return d2h(h, ea, h->red + (size_t)h->n32 * h->n32, sizeof(double) * (size_t)h->d.nA);
 }
 
 int psba_SPDinv_matVec(psba_handle h, double *dpa) {

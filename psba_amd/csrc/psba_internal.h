@@ -62,14 +62,21 @@ struct psba_ctx {
   double *ga = nullptr;         // [nA]                               (g_buffer head)
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
   int nPart = 0;
-  double *red = nullptr;        // [nA*nA + nA]  S | ea, the all-reduce buffer (S_buffer, eab_buffer)
+  // padded reduce buffer Lw[(n32+16)][n32], n32 = nA rounded up to 32: rows < nA = S (row stride
+  // n32), rows nA..n32-1 identity padding, row n32 = ea, rows above zero (S_buffer, eab_buffer)
+  double *red = nullptr;
+  int n32 = 0;
   // K2 (schur) decomposition: camera-row groups x point chunks, one workgroup each
   int nGroups = 0, nChunks = 0; // nGroups == 0: fall back to global atomics
   int glo[psba::MAX_GROUPS + 1] = {0};  // group g owns camera rows [glo[g], glo[g+1])
   int *chunk_tile = nullptr;    // [nChunks+1] first tile of each chunk
+  int *gobs = nullptr;          // [nO] observations ordered by (chunk, camera-row group, index)
+  int *gstart = nullptr;        // [nChunks*nGroups+1] offsets into gobs
   double *slab = nullptr;       // [nChunks][packedN + nA] per-chunk partial -sum(Y W^T) | -sum(Y g_b)
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
+  long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
+  double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
   double *scal = nullptr;       // [NSCAL]
   int *status = nullptr;        // [4]  [0]=singular V, [1]=not SPD
   double *h_scal = nullptr;     // pinned mirror of scal
