@@ -125,12 +125,12 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
 // as plain stores, into the chunk's slab; k_schur_reduce sums the slabs in chunk order.
 // The G workgroups of one chunk are mapped to the same XCD (blockIdx % 8) so that the
 // re-reads of the chunk's W blocks are L2 hits.
-constexpr int SCHUR_THREADS = 512;
+constexpr int SCHUR_THREADS = 1024;
 constexpr int BLK_STRIDE = 37;
 
 struct SchurLdsArgs {
   const double *W, *PV;
-  const int *iidx, *jidx, *ptr, *gobs, *gstart;
+  const int *iidx, *jidx, *ptr, *gobs, *gstart, *chunk_obs0;
   double *slab;
   int *status;
   double *dbg_Y, *dbg_Vinv;
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   const int s0 = p.gstart[chunk * p.nGroups + g];
   const int s1 = (MODE == 4) ? s0 : p.gstart[chunk * p.nGroups + g + 1];
   double keep = 0.0;
+  const int obs0 = p.chunk_obs0[chunk];
   for (int t = s0 + tid; t < s1; t += SCHUR_THREADS) {
-    const int a = p.gobs[t];
+    const unsigned item = (unsigned)p.gobs[t];
+    const int a = obs0 + (int)(item >> 12);
+    const int kfirst = (int)((item >> 4) & 255u), kcount = (int)(item & 15u);
     const int i = p.iidx[a], ja = p.jidx[a];
     const double *pv = p.PV + 9 * (size_t)i;
     double v[6], vi[6];
@@ -202,11 +205,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
         Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
         Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
         Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
-        atomicAdd(&sEa[6 * (ja - lo) + r],
-                  -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
+        if (kfirst == 0)  // the first run of an observation also carries its e_a term
+          atomicAdd(&sEa[6 * (ja - lo) + r],
+                    -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
       }
     }
-    if (DUMP) {
+    if (DUMP && kfirst == 0) {
 #pragma unroll
       for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
     }
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       continue;
     }
     double *rowbase = sPart + BLK_STRIDE * (tri(ja) - Tlo);
-    for (int b = p.ptr[i]; b <= a; b++) {
+    const int bfirst = p.ptr[i] + kfirst;
+    for (int b = bfirst; b < bfirst + kcount; b++) {
       double *blk = rowbase + BLK_STRIDE * p.jidx[b];
       const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)b);
       double wb[18];
@@ -359,6 +364,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   a.ptr = h->ptr;
   a.gobs = h->gobs;
   a.gstart = h->gstart;
+  a.chunk_obs0 = h->chunk_obs0;
   a.slab = h->slab;
   a.status = h->status;
   a.dbg_Y = h->dbg_Y;

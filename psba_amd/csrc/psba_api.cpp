@@ -101,6 +101,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->chunk_tile);
   dev_free(h->gobs);
   dev_free(h->gstart);
+  dev_free(h->chunk_obs0);
   dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->chol_ws);
@@ -301,53 +302,62 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       h->nChunks = nChunks;
       std::vector<int> ct((size_t)nChunks + 1);
       for (int c = 0; c <= nChunks; c++) ct[c] = (int)((long long)d.nTiles * c / nChunks);
-      // compacted observation lists: for every (chunk, group) the observations of the chunk's
-      // points whose camera lies in the group, in observation order
+      // work items: for every (chunk, group) the observations a of the chunk's points whose
+      // camera lies in the group, each split into runs of at most T partner observations
+      // b (the product loop of K2), packed as (a - chunk base) << 12 | first partner << 4 | count.
+      // Bounding the run length bounds the critical path of a workgroup (tracks have a long
+      // tail); inside a list the items are sorted by count, longest first, so that the 64
+      // lanes of a wave run the same number of iterations, and the blocks of 64 are dealt to
+      // the waves of a workgroup forwards and backwards alternately to even out their totals.
       {
         const int G = h->nGroups;
-        std::vector<int> gstart((size_t)nChunks * G + 1, 0), gobs((size_t)n2Dprojs);
+        int T = 4;
+        if (const char *e = getenv("PSBA_SCHUR_TRIPS")) T = atoi(e);
+        if (T < 1) T = 1;
+        if (T > 15) T = 15;
         std::vector<int> grp_of_cam((size_t)nCams);
         for (int g = 0; g < G; g++)
           for (int j = h->glo[g]; j < h->glo[g + 1]; j++) grp_of_cam[j] = g;
+        std::vector<int> gstart((size_t)nChunks * G + 1, 0);
+        std::vector<std::vector<unsigned>> lists((size_t)nChunks * G);
+        std::vector<int> chunk_obs0((size_t)nChunks + 1);
+        for (int c = 0; c <= nChunks; c++) chunk_obs0[c] = ptr[tile_pt[ct[c]]];
         for (int c = 0; c < nChunks; c++) {
-          const int o0 = ptr[tile_pt[ct[c]]], o1 = ptr[tile_pt[ct[c + 1]]];
-          for (int a = o0; a < o1; a++) gstart[(size_t)c * G + grp_of_cam[jidx[a]] + 1]++;
-        }
-        for (size_t k = 0; k < (size_t)nChunks * G; k++) gstart[k + 1] += gstart[k];
-        std::vector<int> fill(gstart.begin(), gstart.end() - 1);
-        for (int c = 0; c < nChunks; c++) {
-          const int o0 = ptr[tile_pt[ct[c]]], o1 = ptr[tile_pt[ct[c + 1]]];
-          for (int a = o0; a < o1; a++) gobs[(size_t)fill[(size_t)c * G + grp_of_cam[jidx[a]]]++] = a;
-        }
-        // inside every (chunk, group) list: sort by trip count of the product loop (position of
-        // the observation inside its point), longest first, so that the 64 lanes of a wave run
-        // the same number of iterations; then deal the blocks of 64 to the 8 waves of a
-        // workgroup forwards and backwards alternately so that the waves' totals even out.
-        {
-          const int WAVES = 8;
-          std::vector<int> tmp;
-          for (size_t k = 0; k < (size_t)nChunks * G; k++) {
-            const int b = gstart[k], e = gstart[k + 1];
-            std::stable_sort(gobs.begin() + b, gobs.begin() + e, [&](int x, int y) {
-              return (x - ptr[iidx[x]]) > (y - ptr[iidx[y]]);
-            });
-            const int nblk = (e - b + 63) / 64;
-            tmp.assign(gobs.begin() + b, gobs.begin() + e);
-            // block q of the sorted list goes to slot (round, wave): forward on even rounds,
-            // backward on odd ones; only whole rounds are permuted (the tail keeps its order)
-            const int fullRounds = nblk / WAVES;
-            for (int r = 1; r < fullRounds; r += 2)
-              for (int w = 0; w < WAVES; w++) {
-                const int src = (r * WAVES + (WAVES - 1 - w)) * 64, dst = (r * WAVES + w) * 64;
-                if (src + 64 <= e - b)
-                  std::copy(tmp.begin() + src, tmp.begin() + src + 64, gobs.begin() + b + dst);
-              }
+          const int o0 = chunk_obs0[c], o1 = chunk_obs0[c + 1];
+          if (o1 - o0 >= (1 << 20))
+            return fail(h, PSBA_E_INVALID, "point chunk with %d observations (max %d)", o1 - o0, 1 << 20);
+          for (int a = o0; a < o1; a++) {
+            auto &L = lists[(size_t)c * G + grp_of_cam[jidx[a]]];
+            const int trips = a - ptr[iidx[a]] + 1;  // partners b = ptr[i] .. a
+            for (int k = 0; k < trips; k += T) {
+              const int cnt = trips - k < T ? trips - k : T;
+              L.push_back(((unsigned)(a - o0) << 12) | ((unsigned)k << 4) | (unsigned)cnt);
+            }
           }
+        }
+        const int WAVES = 16;
+        std::vector<unsigned> gobs;
+        std::vector<unsigned> tmp;
+        for (size_t k = 0; k < lists.size(); k++) {
+          auto &L = lists[k];
+          std::stable_sort(L.begin(), L.end(), [](unsigned x, unsigned y) { return (x & 15u) > (y & 15u); });
+          const int nblk = ((int)L.size() + 63) / 64;
+          tmp = L;
+          const int fullRounds = nblk / WAVES;
+          for (int r = 1; r < fullRounds; r += 2)
+            for (int w = 0; w < WAVES; w++) {
+              const size_t src = (size_t)(r * WAVES + (WAVES - 1 - w)) * 64, dst = (size_t)(r * WAVES + w) * 64;
+              if (src + 64 <= L.size()) std::copy(tmp.begin() + src, tmp.begin() + src + 64, L.begin() + dst);
+            }
+          gstart[k + 1] = gstart[k] + (int)L.size();
+          gobs.insert(gobs.end(), L.begin(), L.end());
         }
         TRY(dev_alloc(h, &h->gobs, gobs.size()));
         TRY(dev_alloc(h, &h->gstart, gstart.size()));
+        TRY(dev_alloc(h, &h->chunk_obs0, chunk_obs0.size()));
         PSBA_HIP(h, hipMemcpy(h->gobs, gobs.data(), sizeof(int) * gobs.size(), hipMemcpyHostToDevice));
         PSBA_HIP(h, hipMemcpy(h->gstart, gstart.data(), sizeof(int) * gstart.size(), hipMemcpyHostToDevice));
+        PSBA_HIP(h, hipMemcpy(h->chunk_obs0, chunk_obs0.data(), sizeof(int) * chunk_obs0.size(), hipMemcpyHostToDevice));
       }
       TRY(dev_alloc(h, &h->chunk_tile, ct.size()));
       TRY(dev_alloc(h, &h->slab, (size_t)nChunks * (h->packedN + d.nA)));

@@ -70,7 +70,8 @@ struct psba_ctx {
   int nGroups = 0, nChunks = 0; // nGroups == 0: fall back to global atomics
   int glo[psba::MAX_GROUPS + 1] = {0};  // group g owns camera rows [glo[g], glo[g+1])
   int *chunk_tile = nullptr;    // [nChunks+1] first tile of each chunk
-  int *gobs = nullptr;          // [nO] observations ordered by (chunk, camera-row group, index)
+  int *gobs = nullptr;          // K2 work items ordered by (chunk, camera-row group): see psba_upload_problem
+  int *chunk_obs0 = nullptr;    // [nChunks+1] first observation of each chunk
   int *gstart = nullptr;        // [nChunks*nGroups+1] offsets into gobs
   double *slab = nullptr;       // [nChunks][packedN + nA] per-chunk partial -sum(Y W^T) | -sum(Y g_b)
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
