@@ -142,6 +142,8 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     if ((tid & 63) == 0) sRed[q][tid >> 6] = v;
   }
   __syncthreads();
+  // one wave-instruction with four lanes: same-address atomics serialise at ~13 ns per
+  // request, so the number of requests (workgroups), not lanes, is what costs
   if (tid < 4) {
     const double v = sRed[tid][0] + sRed[tid][1] + sRed[tid][2] + sRed[tid][3];
     atomicAdd(&p.scal[SC_DP_L2 + tid], v);
@@ -172,8 +174,10 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   a.nA = d.nA;
   a.nTiles = d.nTiles;
   a.cam_terms = h->rank == 0 ? 1 : 0;
-  PSBA_HIP(h, hipMemsetAsync(h->scal + SC_DP_L2, 0, 4 * sizeof(double), h->stream));
-  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  // the fused path's accumulators are zeroed by this try's k_schur_reduce; the sba_func.h mirror
+  // may run K3 more than once per assembly, so it zeroes them here
+  if (dump) PSBA_HIP(h, hipMemsetAsync(h->scal + SC_DP_L2, 0, 4 * sizeof(double), h->stream));
+  int grid = d.nTiles < 512 ? d.nTiles : 512;  // persistent workgroups: few atomic requests
   {
     ProfScope ps(h, PSBA_K_BACKSUB);
     if (dump)

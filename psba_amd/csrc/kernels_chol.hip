@@ -46,7 +46,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 template <int MAXT>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double *x,
                                                              double *linv_store, int n, int n32,
-                                                             int *status, long long *tim) {
+                                                             int *status, int try_id, long long *tim) {
   __shared__ double sD[CB][CB + 1];              // diagonal block, then its Cholesky factor
   __shared__ double sInvD[CB];                   // 1 / diag of the factor
   __shared__ double sX[CB];
@@ -108,23 +108,34 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
     __syncthreads();
     { long long t1 = STAMP(); tS += t1 - t0; }
     {
-      double an[MAXT][CHOL_KU];
+      // groups of 16 columns; A operands are fetched two groups ahead (late block columns
+      // have one tile per wave and many groups: a single group of MFMAs does not cover an L2
+      // round trip)
+      const int nGrp = j / (4 * CHOL_KU);
+      double a1[MAXT][CHOL_KU], a2[MAXT][CHOL_KU];
 #pragma unroll
       for (int q = 0; q < MAXT; q++)
 #pragma unroll
-        for (int u = 0; u < CHOL_KU; u++) an[q][u] = (j > 0) ? arow[q][4 * u] : 0.0;
-      for (int k0 = 0; k0 < j; k0 += 4 * CHOL_KU) {
+        for (int u = 0; u < CHOL_KU; u++) {
+          a1[q][u] = (nGrp > 0 && q < ntile) ? arow[q][4 * u] : 0.0;
+          a2[q][u] = (nGrp > 1 && q < ntile) ? arow[q][4 * CHOL_KU + 4 * u] : 0.0;
+        }
+      for (int gI = 0; gI < nGrp; gI++) {
+        const int k0 = gI * 4 * CHOL_KU;
         double ac[MAXT][CHOL_KU];
 #pragma unroll
         for (int q = 0; q < MAXT; q++)
 #pragma unroll
-          for (int u = 0; u < CHOL_KU; u++) ac[q][u] = an[q][u];
-        if (k0 + 4 * CHOL_KU < j) {
+          for (int u = 0; u < CHOL_KU; u++) {
+            ac[q][u] = a1[q][u];
+            a1[q][u] = a2[q][u];
+          }
+        if (gI + 2 < nGrp) {
 #pragma unroll
           for (int q = 0; q < MAXT; q++)
             if (q < ntile) {
 #pragma unroll
-              for (int u = 0; u < CHOL_KU; u++) an[q][u] = arow[q][k0 + 4 * CHOL_KU + 4 * u];
+              for (int u = 0; u < CHOL_KU; u++) a2[q][u] = arow[q][k0 + 8 * CHOL_KU + 4 * u];
             }
         }
 #pragma unroll
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   }
 
   if (sFail == 1) {
-    if (tid == 0) atomicOr(&status[1], 1);
+    if (tid == 0) status[1] = try_id;
     for (int t = tid; t < n; t += CHOL_THREADS) x[t] = 0.0;
     return;
   }
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   int bad = 0;
   for (int t = tid; t < n; t += CHOL_THREADS)
     if (!isfinite(x[t])) bad = 1;
-  if (bad) atomicOr(&status[1], 1);
+  if (bad) status[1] = try_id;
 }
 
 static bool g_chol_attr = false;
@@ -318,10 +329,10 @@ int launch_chol_solve(psba_ctx *h) {
     ProfScope ps(h, PSBA_K_CHOLESKY);
     if (nTiles <= 3 * CHOL_WAVES)
       hipLaunchKernelGGL(k_chol_solve<3>, dim3(1), dim3(CHOL_THREADS), lds, h->stream, h->red, h->dp,
-                         h->chol_ws, d.nA, n32, h->status, h->chol_tim);
+                         h->chol_ws, d.nA, n32, h->status, h->try_id, h->chol_tim);
     else
       hipLaunchKernelGGL(k_chol_solve<4>, dim3(1), dim3(CHOL_THREADS), lds, h->stream, h->red, h->dp,
-                         h->chol_ws, d.nA, n32, h->status, h->chol_tim);
+                         h->chol_ws, d.nA, n32, h->status, h->try_id, h->chol_tim);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

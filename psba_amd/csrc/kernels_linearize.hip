@@ -108,22 +108,33 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
 }
 
-// one workgroup per camera: sums the partial slabs in slab order, expands sym U_j to the
-// full 6x6 and scales (U by coeff, g_a by coeff_g).
-__global__ __launch_bounds__(256) void k_cam_reduce(const double *campart, int nPart, int nC,
-                                                    double coeff, double coeff_g, double *U,
-                                                    double *ga) {
-  __shared__ double sPart[8][32];
+// one workgroup (1024 threads = 32 slab sequences x 32 entries) per camera: sums the partial
+// slabs in a fixed order, expands sym U_j to the full 6x6 and scales (U by coeff, g_a by coeff_g).
+__global__ __launch_bounds__(1024) void k_cam_reduce(const double *campart, int nPart, int nC,
+                                                     double coeff, double coeff_g, double *U,
+                                                     double *ga) {
+  __shared__ double sPart[32][33];
   const int j = blockIdx.x, e = threadIdx.x & 31, s = threadIdx.x >> 5;
   double acc = 0.0;
-  if (e < CAM_ACC)
-    for (int q = s; q < nPart; q += 8) acc += campart[((size_t)q * nC + j) * CAM_ACC + e];
+  if (e < CAM_ACC) {
+    const double *src = campart + (size_t)j * CAM_ACC + e;
+    const size_t stride = (size_t)nC * CAM_ACC;
+    int q = s;
+    for (; q + 96 < nPart; q += 128) {  // four independent loads in flight, summed in order
+      const double x0 = src[(size_t)q * stride], x1 = src[(size_t)(q + 32) * stride];
+      const double x2 = src[(size_t)(q + 64) * stride], x3 = src[(size_t)(q + 96) * stride];
+      acc += x0;
+      acc += x1;
+      acc += x2;
+      acc += x3;
+    }
+    for (; q < nPart; q += 32) acc += src[(size_t)q * stride];
+  }
   sPart[s][e] = acc;
   __syncthreads();
   if (s == 0 && e < CAM_ACC) {
     double t = sPart[0][e];
-#pragma unroll
-    for (int q = 1; q < 8; q++) t += sPart[q][e];
+    for (int q = 1; q < 32; q++) t += sPart[q][e];
     sPart[0][e] = t;
   }
   __syncthreads();
@@ -169,22 +180,26 @@ __global__ __launch_bounds__(256) void k_residual(const double *camconst, const 
 }
 
 // ---- maxElmOfUV (PSBA/sba_func.cpp:422-444) --------------------------------------------
-__global__ __launch_bounds__(1024) void k_max_diag(const double *U, const double *PV, int nC,
-                                                   int nP, double *out) {
-  __shared__ double sRed[16];
-  double m = -INFINITY;
-  for (int t = threadIdx.x; t < 6 * nC; t += 1024) m = fmax(m, U[36 * (t / 6) + 7 * (t % 6)]);
-  for (int t = threadIdx.x; t < 3 * nP; t += 1024) {
-    const int i = t / 3, r = t % 3;
-    m = fmax(m, PV[9 * (size_t)i + (r == 0 ? 0 : (r == 1 ? 3 : 5))]);
+// diagonals of U and V are sums of squares (times a positive coeff in every caller that asks
+// for the maximum), so the maximum is taken on the bit patterns with an integer atomicMax.
+__global__ __launch_bounds__(256) void k_max_diag(const double *U, const double *PV, int nC,
+                                                  int nP, double *out) {
+  __shared__ double sRed[4];
+  double m = 0.0;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
+  for (int t = gtid; t < 6 * nC; t += gsize) m = fmax(m, U[36 * (t / 6) + 7 * (t % 6)]);
+  for (int i = gtid; i < nP; i += gsize) {
+    const double *v = PV + 9 * (size_t)i;
+    m = fmax(m, fmax(v[0], fmax(v[3], v[5])));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
   if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; k++) m = fmax(m, sRed[k]);
-    *out = m;
+    m = fmax(fmax(sRed[0], sRed[1]), fmax(sRed[2], sRed[3]));
+    atomicMax(reinterpret_cast<unsigned long long *>(out),
+              (unsigned long long)__double_as_longlong(m));
   }
 }
 
@@ -216,7 +231,7 @@ int launch_linearize(psba_ctx *h, bool dump) {
       hipLaunchKernelGGL(k_linearize<true>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
     else
       hipLaunchKernelGGL(k_linearize<false>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
-    hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(256), 0, h->stream, h->campart, h->nPart,
+    hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, h->nPart,
                        d.nC, h->coeff, h->coeff_g, h->U, h->ga);
   }
   PSBA_HIP(h, hipGetLastError());
@@ -228,7 +243,7 @@ int launch_residual(psba_ctx *h, int which, double *ex_out_dev) {
   const int set = which == PSBA_PARAMS_NEW ? 1 - h->cur : h->cur;
   PSBA_HIP(h, hipMemsetAsync(h->scal + SC_COST, 0, sizeof(double), h->stream));
   int grid = (d.nO + 255) / 256;
-  if (grid > 2048) grid = 2048;
+  if (grid > 256) grid = 256;  // one atomic request per workgroup; same-address atomics serialise
   {
     ProfScope ps(h, PSBA_K_RESIDUAL);
     hipLaunchKernelGGL(k_residual, dim3(grid), dim3(256), 0, h->stream, h->camconst, h->cams[set],
@@ -240,7 +255,10 @@ int launch_residual(psba_ctx *h, int which, double *ex_out_dev) {
 }
 
 int launch_max_diag(psba_ctx *h) {
-  hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, h->stream, h->U, h->PV, h->d.nC, h->d.nP,
+  PSBA_HIP(h, hipMemsetAsync(h->scal + SC_MAXDIAG, 0, sizeof(double), h->stream));
+  int grid = (h->d.nP + 255) / 256;
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(k_max_diag, dim3(grid), dim3(256), 0, h->stream, h->U, h->PV, h->d.nC, h->d.nP,
                      h->scal + SC_MAXDIAG);
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

@@ -27,6 +27,7 @@ struct SchurArgs {
   double mu;
   int nC, nA, nTiles;
   int ld;                  // row stride of S (n32)
+  int try_id;
 };
 
 // v1: global fp64 atomics straight into S (lower block triangle).
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
       v[0] += p.mu;
       v[3] += p.mu;
       v[5] += p.mu;
-      if (sym3_inverse(v, vi)) atomicOr(&p.status[0], 1);
+      if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
 #pragma unroll
       for (int k = 0; k < 6; k++) sVi[tid][k] = vi[k];
 #pragma unroll
@@ -135,7 +136,7 @@ struct SchurLdsArgs {
   int *status;
   double *dbg_Y, *dbg_Vinv;
   double mu;
-  int nC, nA, nGroups, nChunks;
+  int nC, nA, nGroups, nChunks, try_id;
   unsigned long long slabStride;  // packedN + nA
   unsigned long long packedN;
   int glo[MAX_GROUPS + 1];
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
     v[0] += p.mu;
     v[3] += p.mu;
     v[5] += p.mu;
-    if (sym3_inverse(v, vi)) atomicOr(&p.status[0], 1);
+    if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
     if (DUMP) {
       double *o = p.dbg_Vinv + 9 * (size_t)i;
       o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
@@ -283,8 +284,10 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nC
                                                       unsigned long long packedN, const double *U,
                                                       const double *ga, double mu_add, int nA,
                                                       int n32, double pad_one, double *S,
-                                                      double *ea) {
+                                                      double *ea, double *scal) {
   __shared__ double sAcc[4][64];
+  // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2)
+  if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
   write_padding(S, nA, n32, pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                 (size_t)gridDim.x * blockDim.x);
   const unsigned long long total = packedN + nA;
@@ -334,7 +337,8 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nC
 // of the per-rank contributions adds mu exactly once.
 __global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, const double *U,
                                                         const double *ga, double mu_add, int nA,
-                                                        int n32, double pad_one) {
+                                                        int n32, double pad_one, double *scal) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
   const size_t n2 = (size_t)nA * nA;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t gsize = (size_t)gridDim.x * blockDim.x;
@@ -374,6 +378,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   a.nA = d.nA;
   a.nGroups = h->nGroups;
   a.nChunks = h->nChunks;
+  a.try_id = h->try_id;
   a.packedN = h->packedN;
   a.slabStride = h->packedN + d.nA;
   size_t worst = 0;
@@ -384,7 +389,6 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
     if (n > worst) worst = n;
   }
   const size_t lds = sizeof(double) * worst;
-  PSBA_HIP(h, hipMemsetAsync(h->status, 0, sizeof(int) * 4, h->stream));
   const int grid = h->nGroups * h->nChunks;
   const double mu_add = h->rank == 0 ? mu : 0.0;
   const size_t total = h->packedN + d.nA;
@@ -409,7 +413,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
     ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
     hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, h->slab, h->nChunks,
                        a.slabStride, a.packedN, h->U, h->ga, mu_add, d.nA, h->n32,
-                       h->rank == 0 ? 1.0 : 0.0, h->red, h->red + (size_t)h->n32 * h->n32);
+                       h->rank == 0 ? 1.0 : 0.0, h->red, h->red + (size_t)h->n32 * h->n32, h->scal);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
@@ -418,6 +422,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
 static bool g_lds_attr_set = false;
 
 int launch_schur(psba_ctx *h, double mu, bool dump) {
+  h->try_id++;  // status words are generation stamps: nothing to zero
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
     if (!g_lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition
@@ -449,8 +454,8 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   a.nC = d.nC;
   a.nA = d.nA;
   a.nTiles = d.nTiles;
+  a.try_id = h->try_id;
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 1) * h->n32, h->stream));
-  PSBA_HIP(h, hipMemsetAsync(h->status, 0, sizeof(int) * 4, h->stream));
   int grid = d.nTiles < 2048 ? d.nTiles : 2048;
   const size_t lds = sizeof(double) * (size_t)d.nA;
   {
@@ -465,7 +470,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   int fgrid = (int)((n2 + 255) / 256);
   if (fgrid > 1024) fgrid = 1024;
   hipLaunchKernelGGL(k_schur_finalize, dim3(fgrid), dim3(256), 0, h->stream, a.S, a.ea, h->U, h->ga,
-                     mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0);
+                     mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0, h->scal);
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
 }

@@ -135,15 +135,16 @@ int psba_create(int device, psba_handle *out) {
   if ((e = hipSetDevice(device)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void **)&h->scal, sizeof(double) * NSCAL)) != hipSuccess ||
-      (e = hipMalloc((void **)&h->status, sizeof(int) * 4)) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * NSCAL)) != hipSuccess ||
-      (e = hipHostMalloc((void **)&h->h_status, sizeof(int) * 4)) != hipSuccess) {
+      false) {
     int rc = fail(nullptr, PSBA_E_HIP, "psba_create: %s", hipGetErrorString(e));
     delete h;
     return rc;
   }
+  // the status stamps live in the tail of the scalar block so that one copy fetches both
+  h->status = reinterpret_cast<int *>(h->scal + 8);
+  h->h_status = reinterpret_cast<int *>(h->h_scal + 8);
   (void)hipMemset(h->scal, 0, sizeof(double) * NSCAL);
-  (void)hipMemset(h->status, 0, sizeof(int) * 4);
   *out = h;
   return PSBA_OK;
 }
@@ -155,9 +156,7 @@ int psba_destroy(psba_handle h) {
   if (h->comm) ncclCommDestroy(h->comm);
   free_problem_buffers(h);
   dev_free(h->scal);
-  dev_free(h->status);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
-  if (h->h_status) (void)hipHostFree(h->h_status);
   for (auto &s : h->spans) {
     (void)hipEventDestroy(s.a);
     (void)hipEventDestroy(s.b);
@@ -341,13 +340,13 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
         for (size_t k = 0; k < lists.size(); k++) {
           auto &L = lists[k];
           std::stable_sort(L.begin(), L.end(), [](unsigned x, unsigned y) { return (x & 15u) > (y & 15u); });
-          const int nblk = ((int)L.size() + 63) / 64;
           tmp = L;
-          const int fullRounds = nblk / WAVES;
-          for (int r = 1; r < fullRounds; r += 2)
+          // only rounds whose 16 blocks of 64 are all complete are permuted
+          const int fullRounds = (int)(L.size() / (size_t)(WAVES * 64));
+          for (int r = 1; r < fullRounds && T > 1; r += 2)
             for (int w = 0; w < WAVES; w++) {
               const size_t src = (size_t)(r * WAVES + (WAVES - 1 - w)) * 64, dst = (size_t)(r * WAVES + w) * 64;
-              if (src + 64 <= L.size()) std::copy(tmp.begin() + src, tmp.begin() + src + 64, L.begin() + dst);
+              std::copy(tmp.begin() + src, tmp.begin() + src + 64, L.begin() + dst);
             }
           gstart[k + 1] = gstart[k] + (int)L.size();
           gobs.insert(gobs.end(), L.begin(), L.end());
@@ -411,9 +410,7 @@ int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D) {
 
 static int fetch_scalars(psba_ctx *h) {
   PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost,
-                             h->stream));
-  PSBA_HIP(h, hipMemcpyAsync(h->h_status, h->status, sizeof(int) * 4, hipMemcpyDeviceToHost,
-                             h->stream));
+                             h->stream));  // scalars and the status stamps (tail of the block)
   PSBA_HIP(h, hipStreamSynchronize(h->stream));
   return PSBA_OK;
 }
@@ -508,12 +505,14 @@ int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
   if (h->comm) {
     RCCL(h, ncclAllReduce(h->scal + SC_DP_L2, h->scal + SC_DP_L2, 4, ncclDouble, ncclSum, h->comm,
                           h->stream));
-    RCCL(h, ncclAllReduce(h->status, h->status, 4, ncclInt, ncclMax, h->comm, h->stream));
+    RCCL(h, ncclAllReduce(h->status, h->status, 2, ncclInt, ncclMax, h->comm, h->stream));
   }
   TRY(fetch_scalars(h));
+  const int st0 = h->h_status[0], st1 = h->h_status[1];
   h->backsubbed = true;
+  h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   if (out) {
-    out->status = (h->h_status[1] ? PSBA_NOT_SPD : 0) | (h->h_status[0] ? PSBA_SINGULAR_V : 0);
+    out->status = (st1 == h->try_id ? PSBA_NOT_SPD : 0) | (st0 == h->try_id ? PSBA_SINGULAR_V : 0);
     out->dp_l2 = h->h_scal[SC_DP_L2];
     out->gain_den = h->h_scal[SC_GAIN_DEN];
     out->new_cost = h->h_scal[SC_NEW_COST];
@@ -642,7 +641,7 @@ int psba_compute_Vinv(psba_handle h, double *Vinv) {
   TRY(reassemble_dump(h));
   TRY(d2h(h, Vinv, h->dbg_Vinv, sizeof(double) * 9 * (size_t)h->d.nP));
   TRY(fetch_scalars(h));
-  return h->h_status[0] ? PSBA_SINGULAR_V : PSBA_OK;
+  return h->h_status[0] == h->try_id ? PSBA_SINGULAR_V : PSBA_OK;
 }
 
 int psba_compute_Wblks(psba_handle h, double coeff, double *Wblks) {
@@ -697,7 +696,7 @@ int psba_SPDinv_matVec(psba_handle h, double *dpa) {
   h->solved = true;
   TRY(fetch_scalars(h));
   TRY(d2h(h, dpa, h->dp, sizeof(double) * (size_t)h->d.nA));
-  return h->h_status[1] ? PSBA_NOT_SPD : PSBA_OK;
+  return h->h_status[1] == h->try_id ? PSBA_NOT_SPD : PSBA_OK;
 }
 
 static int backsub_dump(psba_ctx *h) {

@@ -79,7 +79,10 @@ struct psba_ctx {
   long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
   double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
   double *scal = nullptr;       // [NSCAL]
-  int *status = nullptr;        // [4]  [0]=singular V, [1]=not SPD
+  // [4] generation stamps, never zeroed: [0] == try_id <=> some V_i singular in this try,
+  // [1] == try_id <=> the Cholesky of this try failed.  Lives in scal[8..9]
+  int *status = nullptr;
+  int try_id = 0;
   double *h_scal = nullptr;     // pinned mirror of scal
   int *h_status = nullptr;      // pinned mirror of status
   // debug dumps for the sba_func.h mirror (allocated on first use)

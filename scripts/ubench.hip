@@ -76,6 +76,24 @@ __global__ void k_lds_atomic(double *out, long long *t, int stride, int reps) {
   if (threadIdx.x == 0) t[blockIdx.x] = t1 - t0;
   out[threadIdx.x] = sa[threadIdx.x];
 }
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma_f64(double *out, long long *t, double x, int nacc) {
+  d4 c0 = {0,0,0,0}, c1 = c0, c2 = c0, c3 = c0;
+  double a = x + threadIdx.x, b = x * 0.5;
+  long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < N; i += 4) {
+    if (nacc == 1) {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0); c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0); c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    } else {
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  out[threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3]; if (threadIdx.x == 0) t[0] = t1 - t0;
+}
 int main() {
   double *out; long long *t; hipMalloc(&out, 8 * 1024); hipMalloc(&t, 8 * 1024);
   long long h[8];
@@ -86,7 +104,11 @@ int main() {
     k_rsq_chain<<<1, 64>>>(out, t, 2.0); hipDeviceSynchronize(); rep("dependent rsq+add", N);
     k_lds_rt<<<1, 64>>>(out, t, 1.0); hipDeviceSynchronize(); rep("lds write->read roundtrip", N);
     k_readlane<<<1, 64>>>(out, t, 1.0); hipDeviceSynchronize(); rep("readlane x2 + fma", N);
-    for (int threads : {64, 256, 1024}) for (int stride : {1, 36, 37}) {
+    k_mfma_f64<<<1, 64>>>(out, t, 1.0, 1); hipDeviceSynchronize(); rep("mfma f64 16x16x4 dependent, 1 wave", N);
+    k_mfma_f64<<<1, 64>>>(out, t, 1.0, 4); hipDeviceSynchronize(); rep("mfma f64 16x16x4 4 acc, 1 wave", N);
+    k_mfma_f64<<<1, 512>>>(out, t, 1.0, 4); hipDeviceSynchronize(); rep("mfma f64 16x16x4 4 acc, 8 waves", N);
+    k_mfma_f64<<<1, 1024>>>(out, t, 1.0, 4); hipDeviceSynchronize(); rep("mfma f64 16x16x4 4 acc, 16 waves", N);
+    for (int threads : {1024}) for (int stride : {37}) {
       k_lds_atomic<<<1, threads, 12288 * 8>>>(out, t, stride, 64); hipDeviceSynchronize();
       hipMemcpy(h, t, 8, hipMemcpyDeviceToHost);
       printf("lds atomicAdd f64 threads=%4d stride=%2d: %8lld cycles, %.2f cycles per wave-instr\n", threads, stride, h[0], (double)h[0] / (64 * 8 * (threads / 64)));

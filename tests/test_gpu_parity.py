@@ -201,3 +201,34 @@ def test_verbs_before_upload_fail_cleanly():
     with pytest.raises(psba_amd.PsbaError):
         h.residual(0)
     h.close()
+
+
+def test_venice_sized_parity_away_from_the_initial_point(gpu):
+    """Full-size check (52 cameras, 64k points, 347k observations, several camera-row groups
+    and 80 point chunks in K2) at parameters with non-zero local rotations: S, ea, dp and the
+    LM trajectory against the oracle."""
+    import psba_amd.synth as synth
+    prob = synth.venice_shaped()
+    o = Oracle(prob)
+    o.levmar(max_iter=3, tr_handoff=False)  # move away from v = 0
+    gpu.upload_problem(prob)
+    gpu.set_params(o.cams, o.pts)
+    lin = o.linearize()
+    for mu in (1e-3 * lin["maxdiag"], 1.0):
+        sch = o.schur(lin, mu)
+        gpu.linearize(1.0, 1.0)
+        gpu.update_UV(mu)
+        close(gpu.compute_S(), sch["S"], 1e-11, "S")
+        close(gpu.compute_ea(), sch["eab"][: o.nA], 1e-9, "ea")
+        ret, dp, _ = o.solve(lin, sch)
+        rc, dpa = gpu.SPDinv_matVec()
+        assert rc == 0 and ret == 0.0
+        # cond(S) grows as mu falls: compare through the residual of the linear system instead
+        r = sch["S"] @ dpa - sch["eab"][: o.nA]
+        assert np.abs(r).max() <= 1e-9 * np.abs(sch["eab"][: o.nA]).max()
+        gpu.restore_UVdiag()
+    gpu.upload_problem(prob)
+    res, log = gpu.levmar(max_iter=12, tr_handoff=False)
+    ores, olog = Oracle(prob).levmar(max_iter=12, tr_handoff=False)
+    assert res.tries == ores.tries
+    assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
