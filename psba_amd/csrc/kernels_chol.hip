@@ -28,10 +28,8 @@
 namespace psba {
 
 constexpr int CB = 16;  // block column width (one MFMA column tile)
-constexpr int CT = CB / 16;
 constexpr int CHOL_THREADS = 512;
 constexpr int CHOL_WAVES = CHOL_THREADS / 64;
-constexpr int CHOL_KU = 4;  // k-steps (of 4) per prefetch group: 16 columns, divides every j
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double dcb __attribute__((ext_vector_type(CB)));  // SSA vector: never demoted to scratch
@@ -42,6 +40,97 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
+// Phase A for one wave: NT row tiles (tile index T0, T0+8, ...) of block column j.
+// acc = C - L[rows, 0:j] L[j:j+16, 0:j]^T with two accumulators per tile (even / odd k-steps:
+// a dependent v_mfma_f64_16x16x4 chain costs ~138 cycles per link, independent ones issue
+// every 32), A operands fetched two 16-column groups ahead, B operands from LDS.  No branch
+// sits between the MFMAs: the number of tiles is a template parameter chosen by a
+// wave-uniform switch.  The finished tiles go back in place, the diagonal tile into sD.
+template <int NT>
+__device__ __forceinline__ void chol_update_tiles(double *Lw, const double *sB, double (*sD)[CB + 1],
+                                                  int ld, int ldb, int j, int T0, int firstTile,
+                                                  int li, int lk, long long *st) {
+  long long s0 = st ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  d4 acc0[NT], acc1[NT], acc2[NT], acc3[NT];
+  // k-slot assignment: in the group of 16 columns starting at k0, MFMA step t (0..3) pairs
+  // lane slot lk with column k0 + 4 lk + t.  Any pairing is valid as long as A and B agree,
+  // and this one lets every lane fetch its four A values as ONE 32-byte piece of its row, so
+  // a wave-load covers 16 rows x 128 B exactly (8-byte pieces at a 32-byte stride moved four
+  // times the bytes through L1 and made this loop bandwidth-bound).
+  const double4 *arow[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    const int T = T0 + q * CHOL_WAVES;
+    arow[q] = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * T + li) * ld + 4 * lk);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      acc0[q][r] = Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li];
+      acc1[q][r] = 0.0;
+      acc2[q][r] = 0.0;
+      acc3[q][r] = 0.0;
+    }
+  }
+  const int nGrp = j / 16;
+  const double4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  double4 a1[NT], a2[NT];
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    a1[q] = (nGrp > 0) ? arow[q][0] : zero4;
+    a2[q] = (nGrp > 1) ? arow[q][4] : zero4;  // + 16 columns
+  }
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long s1 = (long long)__builtin_amdgcn_s_memtime();
+    st[0] += s1 - s0;
+    s0 = s1;
+  }
+  for (int gI = 0; gI < nGrp; gI++) {
+    const int k0 = 16 * gI;
+    double4 ac[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      ac[q] = a1[q];
+      a1[q] = a2[q];
+    }
+    if (gI + 2 < nGrp) {
+#pragma unroll
+      for (int q = 0; q < NT; q++) a2[q] = arow[q][4 * (gI + 2)];
+    }
+    const double *bp = sB + li * ldb + k0 + 4 * lk;
+    const double b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+    // four independent accumulators per tile (one per k-slot step): a dependent MFMA chain
+    // costs ~138 cycles per link, so each accumulator sees one link per group
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      acc0[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q].x, b0, acc0[q], 0, 0, 0);
+      acc1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q].y, b1, acc1[q], 0, 0, 0);
+      acc2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q].z, b2, acc2[q], 0, 0, 0);
+      acc3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q].w, b3, acc3[q], 0, 0, 0);
+    }
+  }
+  if (st) {
+    const long long s1 = (long long)__builtin_amdgcn_s_memtime();
+    st[1] += s1 - s0;
+    s0 = s1;
+  }
+#pragma unroll
+  for (int q = 0; q < NT; q++) {
+    const int T = T0 + q * CHOL_WAVES;
+    if (T == firstTile) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sD[lk + 4 * r][li] = (acc0[q][r] + acc1[q][r]) + (acc2[q][r] + acc3[q][r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li] = (acc0[q][r] + acc1[q][r]) + (acc2[q][r] + acc3[q][r]);
+    }
+  }
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[2] += (long long)__builtin_amdgcn_s_memtime() - s0;
+  }
+}
+
 // MAXT = row tiles a wave may own in one block column: ceil((n32/16 + 1) / CHOL_WAVES)
 template <int MAXT>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double *x,
@@ -50,13 +139,15 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   __shared__ double sD[CB][CB + 1];              // diagonal block, then its Cholesky factor
   __shared__ double sInvD[CB];                   // 1 / diag of the factor
   __shared__ double sX[CB];
+  extern __shared__ double sDyn[];  // sB [CB][ldb], then the diagonal blocks of L for the backward solve
   __shared__ double sCol[CB];
   __shared__ int sFail;
-  extern __shared__ double sB[];  // [32][ldb] rows j..j+31 of L, columns < j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int ld = n32;
   const int ldb = n32 + 1;
+  double *sB = sDyn;                       // [CB][ldb] rows j..j+15 of L, columns < j
+  double *sDiag = sDyn + (size_t)CB * ldb;  // [n32/CB][CB][CB+1]
   const int nTiles = n32 / 16 + 1;  // row tiles incl. the e_a tile
   if (tid == 0) sFail = 0;
   // Pull the whole matrix into this XCD's L2 first, with as many lines in flight as the
@@ -80,6 +171,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   }
   __syncthreads();
   long long tA = 0, tB = 0, tC = 0, tBack = 0, t0 = 0, tF = 0, tS = 0;
+  long long st3[3] = {0, 0, 0};
 #define STAMP() (tim ? (long long)__builtin_amdgcn_s_memtime() : 0)
 
   for (int j = 0; j < n32; j += CB) {
@@ -90,68 +182,22 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
       const double *src = Lw + (size_t)(j + r) * ld;
       for (int c = lane; c < j; c += 64) sB[r * ldb + c] = src[c];
     }
-    d4 acc[MAXT][CT];
-    const double *arow[MAXT];
-    int ntile = 0;
-#pragma unroll
-    for (int q = 0; q < MAXT; q++) {
-      const int T = firstTile + wave + q * CHOL_WAVES;
-      const int Tc = T < nTiles ? T : nTiles - 1;  // clamp: harmless duplicate work, never stored
-      if (T < nTiles) ntile = q + 1;
-      arow[q] = Lw + (size_t)(16 * Tc + li) * ld + lk;
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          acc[q][ct][r] = Lw[(size_t)(16 * Tc + lk + 4 * r) * ld + j + 16 * ct + li];
-    }
     __syncthreads();
-    { long long t1 = STAMP(); tS += t1 - t0; }
     {
-      // groups of 16 columns; A operands are fetched two groups ahead (late block columns
-      // have one tile per wave and many groups: a single group of MFMAs does not cover an L2
-      // round trip)
-      const int nGrp = j / (4 * CHOL_KU);
-      double a1[MAXT][CHOL_KU], a2[MAXT][CHOL_KU];
-#pragma unroll
-      for (int q = 0; q < MAXT; q++)
-#pragma unroll
-        for (int u = 0; u < CHOL_KU; u++) {
-          a1[q][u] = (nGrp > 0 && q < ntile) ? arow[q][4 * u] : 0.0;
-          a2[q][u] = (nGrp > 1 && q < ntile) ? arow[q][4 * CHOL_KU + 4 * u] : 0.0;
-        }
-      for (int gI = 0; gI < nGrp; gI++) {
-        const int k0 = gI * 4 * CHOL_KU;
-        double ac[MAXT][CHOL_KU];
-#pragma unroll
-        for (int q = 0; q < MAXT; q++)
-#pragma unroll
-          for (int u = 0; u < CHOL_KU; u++) {
-            ac[q][u] = a1[q][u];
-            a1[q][u] = a2[q][u];
-          }
-        if (gI + 2 < nGrp) {
-#pragma unroll
-          for (int q = 0; q < MAXT; q++)
-            if (q < ntile) {
-#pragma unroll
-              for (int u = 0; u < CHOL_KU; u++) a2[q][u] = arow[q][k0 + 8 * CHOL_KU + 4 * u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CHOL_KU; u++) {
-          double bq[CT];
-#pragma unroll
-          for (int ct = 0; ct < CT; ct++) bq[ct] = sB[(16 * ct + li) * ldb + k0 + 4 * u + lk];
-#pragma unroll
-          for (int q = 0; q < MAXT; q++) {
-            if (q < ntile) {  // wave-uniform: late block columns have fewer row tiles than slots
-#pragma unroll
-              for (int ct = 0; ct < CT; ct++)
-                acc[q][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ac[q][u], bq[ct], acc[q][ct], 0, 0, 0);
-            }
-          }
-        }
+      long long t1 = STAMP();
+      tS += t1 - t0;
+    }
+    {
+      // row tiles of this block column: firstTile .. nTiles-1, dealt to the waves round-robin
+      const int T0 = firstTile + wave;
+      long long *stp = (tim && tid == 0) ? st3 : nullptr;
+      const int ntile = T0 < nTiles ? (nTiles - 1 - T0) / CHOL_WAVES + 1 : 0;
+      switch (ntile) {
+        case 1: chol_update_tiles<1>(Lw, sB, sD, ld, ldb, j, T0, firstTile, li, lk, stp); break;
+        case 2: chol_update_tiles<2>(Lw, sB, sD, ld, ldb, j, T0, firstTile, li, lk, stp); break;
+        case 3: chol_update_tiles<3>(Lw, sB, sD, ld, ldb, j, T0, firstTile, li, lk, stp); break;
+        case 4: if (MAXT >= 4) chol_update_tiles<4>(Lw, sB, sD, ld, ldb, j, T0, firstTile, li, lk, stp); break;
+        default: break;
       }
     }
     {
@@ -159,27 +205,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
       tA += t1 - t0;
       t0 = t1;
     }
-    // ---- phase B: diagonal block -> LDS, factor + invert in one wave ---------------------
-    // the diagonal block lives in row tiles firstTile, firstTile+1 = waves 0 and 1, q = 0.
-    // The other updated tiles go back to the matrix in place (phase C re-reads them in the
-    // A-operand layout), so no accumulator stays live across the serial phase.
-#pragma unroll
-    for (int q = 0; q < MAXT; q++) {
-      const int T = firstTile + wave + q * CHOL_WAVES;
-      if (q < ntile && T >= firstTile + CT) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 * ct + li] = acc[q][ct][r];
-      }
-    }
-    if (wave < CT) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) sD[16 * wave + lk + 4 * r][16 * ct + li] = acc[0][ct][r];
-    }
+    // ---- phase B: the diagonal block (now in sD) is factored by one wave -------------------
     __syncthreads();
     if (wave == 0) {
       // lane r < 32 keeps row r of the block in registers (an SSA vector); the pivot and the
@@ -228,6 +254,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
     for (int t = tid; t < CB * CB; t += CHOL_THREADS) {
       const int r = t / CB, c = t % CB;
       Lw[(size_t)(j + r) * ld + j + c] = sD[r][c];
+      sDiag[(size_t)(j / CB) * CB * (CB + 1) + r * (CB + 1) + c] = sD[r][c];
     }
     // ---- phase C: X L_dd^T = C for the rows below the diagonal block, one thread per row:
     // forward substitution with the row in registers, L_dd from LDS (uniform addresses
@@ -264,15 +291,27 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   }
 
   // ---- backward solve  L^T x = y  (y = L^-1 e_a now sits in row n32) ----------------------
+  // per block J (descending): one wave solves L_dd^T x_J = y_J by substitution (L_dd from LDS),
+  // then all threads apply y[c] -= sum_r L[j+r][c] x_J[r] for c < j.  The 16 L values each
+  // thread needs for that update do not depend on x, so they are fetched one block ahead.
   double *y = Lw + (size_t)n32 * ld;
+  double lnext[CB];
+#pragma unroll
+  for (int r = 0; r < CB; r++) lnext[r] = (tid < n32 - CB) ? Lw[(size_t)(n32 - CB + r) * ld + tid] : 0.0;
   for (int j = n32 - CB; j >= 0; j -= CB) {
-    // L_dd^T x_J = y_J by backward substitution in one wave: lane r holds z_r and column r
-    // of L_dd (row k of L_dd is read across lanes, coalesced)
+    double lcur[CB];
+#pragma unroll
+    for (int r = 0; r < CB; r++) lcur[r] = lnext[r];
+    if (j >= CB) {
+#pragma unroll
+      for (int r = 0; r < CB; r++) lnext[r] = (tid < j - CB) ? Lw[(size_t)(j - CB + r) * ld + tid] : 0.0;
+    }
     if (wave == 0) {
       const int r = lane & (CB - 1);
+      const double *Ld = sDiag + (size_t)(j / CB) * CB * (CB + 1);
       dcb lcol;
 #pragma unroll
-      for (int k = 0; k < CB; k++) lcol[k] = Lw[(size_t)(j + k) * ld + j + r];  // L_dd[k][r]
+      for (int k = 0; k < CB; k++) lcol[k] = Ld[k * (CB + 1) + r];  // L_dd[k][r]
       double z = y[j + r];
 #pragma clang loop unroll(full)
       for (int k = CB - 1; k >= 0; k--) {
@@ -286,12 +325,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
       }
     }
     __syncthreads();
-    // y[c] -= sum_r L[j+r][c] x_J[r]  for c < j
-    for (int c = tid; c < j; c += CHOL_THREADS) {
+    if (tid < j) {  // CHOL_THREADS >= n32 is checked at launch
       double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < CB; r++) acc += Lw[(size_t)(j + r) * ld + c] * sX[r];
-      y[c] -= acc;
+      for (int r = 0; r < CB; r++) acc += lcur[r] * sX[r];
+      y[tid] -= acc;
     }
     __syncthreads();
   }
@@ -303,6 +341,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
     tim[3] = tBack;
     tim[4] = tF;
     tim[5] = tS;
+    tim[6] = st3[0] + (st3[1] << 0) * 0;
+    tim[6] = st3[0];
+    tim[7] = st3[1];
   }
   int bad = 0;
   for (int t = tid; t < n; t += CHOL_THREADS)
@@ -316,8 +357,9 @@ int launch_chol_solve(psba_ctx *h) {
   const Dims &d = h->d;
   const int n32 = h->n32;
   const int nTiles = n32 / 16 + 1;
-  const size_t lds = sizeof(double) * CB * (size_t)(n32 + 1);
-  if (nTiles > 4 * CHOL_WAVES || 16 * nTiles > CHOL_THREADS + CB || lds > 163840 - 20 * 1024)
+  const size_t lds = sizeof(double) * ((size_t)CB * (n32 + 1) + (size_t)(n32 / CB) * CB * (CB + 1));
+  if (nTiles > 4 * CHOL_WAVES || 16 * nTiles > CHOL_THREADS + CB || n32 > CHOL_THREADS ||
+      lds > 163840 - 20 * 1024)
     return fail(h, PSBA_E_INVALID, "dense solve supports 6*nCams <= 480 for now (got %d)", d.nA);
   if (!g_chol_attr) {
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;

@@ -490,8 +490,8 @@ int psba_schur_solve(psba_handle h) {
     long long t[8];
     PSBA_HIP(h, hipMemcpyAsync(t, h->chol_tim, sizeof t, hipMemcpyDeviceToHost, h->stream));
     PSBA_HIP(h, hipStreamSynchronize(h->stream));
-    fprintf(stderr, "chol cycles: update %lld (staging %lld) diag %lld (factor %lld) trsm %lld backward %lld\n",
-            t[0], t[5], t[1], t[4], t[2], t[3]);
+    fprintf(stderr, "chol cycles: update %lld (staging %lld, tile loads %lld, mfma loop %lld) diag %lld (factor %lld) trsm %lld backward %lld\n",
+            t[0], t[5], t[6], t[7], t[1], t[4], t[2], t[3]);
   }
   h->assembled = false;  // S is overwritten by its factor
   h->solved = true;
