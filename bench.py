@@ -77,11 +77,21 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     prob, data_kind = load_workload(args.workload, rank, world)
-    h = psba_amd.Psba(local_rank)
+    # PSBA_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (rehearsal of the N>1 path on a 1-GPU box)
+    h = psba_amd.Psba(0 if os.environ.get("PSBA_BENCH_ONE_DEVICE") else local_rank)
     if world > 1:
         uid = [psba_amd.Psba.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        h.comm_init(world, rank, uid[0])
+        # RCCL prints a version banner on stdout at communicator creation; stdout carries exactly
+        # one JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            h.comm_init(world, rank, uid[0])
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     h.upload_problem(prob)
     cams0, pts0 = np.array(prob["cams"], copy=True), np.array(prob["pts"], copy=True)
 

@@ -180,6 +180,15 @@ int psba_partition_points(int n3Dpts, const int *iidx, int n2Dprojs, int nranks,
 int psba_comm_unique_id(void *id128);
 int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128);
 int psba_comm_rank(psba_handle h, int *nranks, int *rank);
+/* Bring-your-own reduction (MPI, host staging, tests): declare the rank layout without an RCCL
+ * communicator, then sum the reduce buffer yourself between psba_schur_assemble and
+ * psba_schur_solve.  The buffer is the padded [S | ea] block: psba_reduce_buffer_size doubles.
+ * With a layout but no communicator psba_backsub / psba_residual / psba_max_diag return this
+ * rank's partial sums (camera terms counted on rank 0 only), to be summed by the caller. */
+int psba_set_rank_layout(psba_handle h, int nranks, int rank);
+int psba_reduce_buffer_size(psba_handle h, long long *n_doubles);
+int psba_get_reduce_buffer(psba_handle h, double *out);
+int psba_set_reduce_buffer(psba_handle h, const double *in);
 
 /* ---- on-disk format: readInitialSBAEstimate (PSBA/readparams.cpp:444-519) -------------
  * Reads an sba-format cams file (7 columns q,t with fixedK[5] replicated, or 12 columns

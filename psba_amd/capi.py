@@ -89,6 +89,10 @@ SIGNATURES = [
     ("psba_comm_unique_id", C.c_int, [C.c_void_p]),
     ("psba_comm_init", C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     ("psba_comm_rank", C.c_int, [_h, _ip, _ip]),
+    ("psba_set_rank_layout", C.c_int, [_h, C.c_int, C.c_int]),
+    ("psba_reduce_buffer_size", C.c_int, [_h, C.POINTER(C.c_longlong)]),
+    ("psba_get_reduce_buffer", C.c_int, [_h, _dp]),
+    ("psba_set_reduce_buffer", C.c_int, [_h, _dp]),
     ("psba_read_problem", C.c_int, [C.c_char_p, C.c_char_p, _dp, C.POINTER(CProblem)]),
     ("psba_free_problem", None, [C.POINTER(CProblem)]),
     ("psba_profile_enable", C.c_int, [_h, C.c_int]),
@@ -325,6 +329,24 @@ class Psba:
     def comm_init(self, nranks, rank, uid):
         buf = C.create_string_buffer(uid, 128)
         self._ck(lib.psba_comm_init(self._h, nranks, rank, buf))
+
+    def set_rank_layout(self, nranks, rank):
+        self._ck(lib.psba_set_rank_layout(self._h, nranks, rank))
+
+    def reduce_buffer_size(self):
+        n = C.c_longlong()
+        self._ck(lib.psba_reduce_buffer_size(self._h, C.byref(n)))
+        return n.value
+
+    def get_reduce_buffer(self):
+        out = np.empty(self.reduce_buffer_size())
+        self._ck(lib.psba_get_reduce_buffer(self._h, _d(out)))
+        return out
+
+    def set_reduce_buffer(self, buf):
+        b = _c(buf).reshape(-1)
+        assert b.size == self.reduce_buffer_size()
+        self._ck(lib.psba_set_reduce_buffer(self._h, _d(b)))
 
     # ---- measurement ----
     def profile_enable(self, on=True):

@@ -786,6 +786,38 @@ int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128) {
   return PSBA_OK;
 }
 
+int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
+  CHECK_H(h);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSBA_E_INVALID, "bad rank %d / %d", rank, nranks);
+  if (h->comm) return fail(h, PSBA_E_STATE, "a communicator is attached: its layout is fixed");
+  h->nranks = nranks;
+  h->rank = rank;
+  return PSBA_OK;
+}
+
+int psba_reduce_buffer_size(psba_handle h, long long *n_doubles) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (n_doubles) *n_doubles = (long long)(h->n32 + 1) * h->n32;
+  return PSBA_OK;
+}
+
+int psba_get_reduce_buffer(psba_handle h, double *out) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  return d2h(h, out, h->red, sizeof(double) * (size_t)(h->n32 + 1) * h->n32);
+}
+
+int psba_set_reduce_buffer(psba_handle h, const double *in) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  if (!in) return fail(h, PSBA_E_INVALID, "null buffer");
+  PSBA_HIP(h, hipMemcpyAsync(h->red, in, sizeof(double) * (size_t)(h->n32 + 1) * h->n32,
+                             hipMemcpyHostToDevice, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  return PSBA_OK;
+}
+
 int psba_comm_rank(psba_handle h, int *nranks, int *rank) {
   CHECK_H(h);
   if (nranks) *nranks = h->nranks;

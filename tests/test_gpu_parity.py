@@ -232,3 +232,89 @@ def test_venice_sized_parity_away_from_the_initial_point(gpu):
     ores, olog = Oracle(prob).levmar(max_iter=12, tr_handoff=False)
     assert res.tries == ores.tries
     assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
+
+
+def test_single_rank_communicator_runs_the_rccl_path(problems, golden):
+    """psba_comm_init with one rank: the all-reduce of [S | ea], of the try scalars and of the
+    status words goes through RCCL on the handle's stream; results must not change."""
+    import psba_amd
+    h = psba_amd.Psba(0)
+    h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
+    prob = problems["54cams"]
+    h.upload_problem(prob)
+    res, log = h.levmar(max_iter=6, tr_handoff=False)
+    acc = log[log[:, 4] > 0]
+    g = golden["problems"]["54cams"]
+    for k, want in enumerate(g["err_after_itno"]):
+        assert abs(acc[k, 1] - want) <= 1e-9 * want
+    assert abs(res.mu0 - g["mu0"]) <= 1e-12 * g["mu0"]
+    h.close()
+
+
+def test_points_seen_by_one_camera_and_empty_tail(gpu):
+    """Degenerate tracks: points with a single observation (V_i rank 2: only mu makes it
+    invertible) must not break the path."""
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=9, n_pts=300, mean_track=1.6, seed=11, min_track=1, max_track=9)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    gpu.linearize(1.0, 1.0)
+    gpu.update_UV(mu)
+    sch = o.schur(lin, mu)
+    close(gpu.compute_S(), sch["S"], 1e-11, "S")
+    _, dp, _ = o.solve(lin, sch)
+    gpu.SPDinv_matVec()
+    close(gpu.compute_dpb(), dp, 1e-8, "dp")
+
+
+def test_two_rank_layout_emulated_on_one_gpu(problems):
+    """The rank-dependent kernel logic (mu*I, identity padding and camera terms on rank 0 only,
+    per-rank partial U / g_a folded into the reduce buffer) with the all-reduce done by hand:
+    two handles on one GPU, each owning a point shard (psba_set_rank_layout +
+    psba_get/set_reduce_buffer), must reproduce the single-handle try."""
+    import psba_amd
+    from psba_amd import capi
+    prob = problems["54cams"]
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, _ = o.solve(lin, sch)
+    ref = psba_amd.Psba(0)
+    ref.upload_problem(prob)
+    ref.linearize(1.0, 1.0)
+    ref.schur_assemble(mu); ref.schur_reduce(); ref.schur_solve()
+    want = ref.backsub(mu)
+    hs = []
+    for r in range(2):
+        h = psba_amd.Psba(0)
+        h.set_rank_layout(2, r)
+        h.upload_problem(capi.shard_problem(prob, 2, r))
+        h.linearize(1.0, 1.0)
+        h.schur_assemble(mu)
+        hs.append(h)
+    total = hs[0].get_reduce_buffer() + hs[1].get_reduce_buffer()
+    n32 = (o.nA + 31) // 32 * 32
+    M = total.reshape(n32 + 1, n32)
+    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S summed over ranks")
+    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea summed over ranks")
+    assert np.array_equal(M[o.nA: n32, o.nA:], np.eye(n32 - o.nA))  # identity padding exactly once
+    got = np.zeros(4)
+    for h in hs:
+        h.set_reduce_buffer(total)
+        h.schur_solve()
+        sc = h.backsub(mu)
+        assert sc.status == 0
+        got += [sc.dp_l2, sc.gain_den, sc.new_cost, sc.newp_l2]
+    for g, w in zip(got, [want.dp_l2, want.gain_den, want.new_cost, want.newp_l2]):
+        assert abs(g - w) <= 1e-9 * abs(w), (g, w)
+    # proposed cameras are replicated, proposed points are the shards
+    c0, p0 = hs[0].get_params(1)
+    c1, p1 = hs[1].get_params(1)
+    assert np.array_equal(c0, c1)
+    newp = np.r_[o.cams, o.pts] + dp
+    close(np.r_[c0.reshape(-1), p0.reshape(-1), p1.reshape(-1)], newp, 1e-9, "proposal")
+    for h in hs + [ref]:
+        h.close()
