@@ -116,7 +116,9 @@ def main():
     # warmup: W untimed LM iterations
     if args.warmup > 0:
         run_steps(args.warmup)
-    h.profile_enable(True)
+    # HIP events on the graded kernel only during the timed region (every timed launch costs two
+    # event records on the stream); the other kernel classes are timed in an extra pass afterwards
+    h.profile_enable(int(os.environ.get("PSBA_BENCH_PROF_MASK", 1 << capi.K_SCHUR)))
     h.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -136,17 +138,22 @@ def main():
     else:
         n_pts_total = prob["nP"]
     kern = {}
+    ms, n = h.profile_get(capi.K_SCHUR)
+    kern["schur"] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
+    h.profile_enable(True)  # untimed extra pass: per-kernel times of every class
+    h.profile_reset()
+    run_steps(min(args.steps, args.segment))
     for k, name in enumerate(capi.KERNEL_NAMES):
         ms, n = h.profile_get(k)
-        if n:
+        if n and name != "schur":
             kern[name] = {"avg_us": 1e3 * ms / n, "launches": n}
     h.profile_enable(False)
 
     out = None
     if rank == 0:
         sch_bytes = h.algorithmic_bytes(capi.K_SCHUR)
-        sch_us = kern["schur"]["avg_us"]
-        achieved = sch_bytes / (sch_us * 1e-6) / 1e9
+        sch_us = kern.get("schur", {"avg_us": float("nan")})["avg_us"]
+        achieved = sch_bytes / (sch_us * 1e-6) / 1e9 if sch_us == sch_us and sch_us > 0 else float("nan")
         out = {
             "metric": "M-observations/sec through Jacobian+Schur build+solve (ms/LM-iter in ms_per_step)",
             "value": n_obs_total * steps_done / elapsed / 1e6,

@@ -214,6 +214,8 @@ void psba_free_problem(psba_problem *p);
 #define PSBA_K_ALLREDUCE 5
 #define PSBA_K_SCHUR_REDUCE 6 /* slab sum + U + mu I + mirror that finishes S after PSBA_K_SCHUR */
 #define PSBA_K_COUNT 7
+/* on < 0: time every kernel class; on > 0: bit mask (1 << PSBA_K_*) of the classes to time;
+ * 0: off.  Every timed launch costs two event records on the stream (~3 us). */
 int psba_profile_enable(psba_handle h, int on);
 int psba_profile_reset(psba_handle h);
 /* total_ms and launch count per kernel class since the last reset (synchronises) */

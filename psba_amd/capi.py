@@ -350,7 +350,8 @@ class Psba:
 
     # ---- measurement ----
     def profile_enable(self, on=True):
-        self._ck(lib.psba_profile_enable(self._h, int(on)))
+        """True: every kernel class; False: off; int > 0: bit mask of 1 << K_*."""
+        self._ck(lib.psba_profile_enable(self._h, -1 if on is True else int(on)))
 
     def profile_reset(self):
         self._ck(lib.psba_profile_reset(self._h))

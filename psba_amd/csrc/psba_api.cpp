@@ -33,7 +33,7 @@ int fail(psba_ctx *h, int code, const char *fmt, ...) {
 }
 
 ProfScope::ProfScope(psba_ctx *hh, int kind) : h(hh) {
-  if (!h->prof) return;
+  if (!(h->prof & (1u << kind))) return;
   if (h->spans_used == h->spans.size()) {
     psba_ctx::Span s;
     s.kind = kind;
@@ -843,7 +843,7 @@ static int prof_flush(psba_ctx *h) {
 int psba_profile_enable(psba_handle h, int on) {
   CHECK_H(h);
   TRY(prof_flush(h));
-  h->prof = on != 0;
+  h->prof = on < 0 ? ~0u : (unsigned)on;  // negative: every class; otherwise a bit mask of classes
   return PSBA_OK;
 }
 

@@ -96,7 +96,7 @@ struct psba_ctx {
   bool mu_applied = false;      // update_UV called (fine-grained mirror only)
 
   // ---- profiling ----
-  bool prof = false;
+  unsigned prof = 0;            // bit k set: time kernel class k with HIP events
   struct Span { hipEvent_t a, b; int kind; };
   std::vector<Span> spans;
   size_t spans_used = 0;
