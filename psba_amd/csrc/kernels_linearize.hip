@@ -28,6 +28,7 @@ struct LinArgs {
 template <bool DUMP>
 __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   __shared__ double sBE[TILE_OBS][8];  // B(6) | e(2) per observation of the tile
+  __shared__ double sW[TILE_OBS * 19];  // W blocks of the tile
   extern __shared__ double sAcc[];     // [nC][27]
   const int tid = threadIdx.x;
   const int nAcc = p.nC * CAM_ACC;
@@ -57,8 +58,10 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
 #pragma unroll
         for (int k = 0; k < 6; k++) p.dbg_JB[6 * (size_t)a + k] = B[k];
       }
-      // W_ij = coeff * A^T B, 6x3 row-major
-      double *w = p.W + 18 * (size_t)a;
+      // W_ij = coeff * A^T B, 6x3 row-major: staged in LDS (row stride 19 doubles: odd, so the
+      // 64 lanes of a store hit distinct banks) and written to HBM as one contiguous run per
+      // tile after the barrier, instead of 144-byte pieces at a 144-byte stride per lane
+      double *w = sW + 19 * tid;
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -78,6 +81,11 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
       for (int r = 0; r < 6; r++) atomicAdd(&acc[21 + r], A[r] * e[0] + A[6 + r] * e[1]);
     }
     __syncthreads();
+    {
+      double *dst = p.W + 18 * (size_t)o0;
+      const int n = 18 * (o1 - o0);
+      for (int t = tid; t < n; t += TILE_OBS) dst[t] = sW[19 * (t / 18) + t % 18];
+    }
     // one thread per point: V_i (sym6) and g_b,i in camera-ascending order
     const int i = p0 + tid;
     if (i < p1) {

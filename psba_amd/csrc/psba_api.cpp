@@ -339,11 +339,12 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
         std::vector<unsigned> tmp;
         for (size_t k = 0; k < lists.size(); k++) {
           auto &L = lists[k];
-          std::stable_sort(L.begin(), L.end(), [](unsigned x, unsigned y) { return (x & 15u) > (y & 15u); });
+          if (!getenv("PSBA_SCHUR_NOSORT"))
+            std::stable_sort(L.begin(), L.end(), [](unsigned x, unsigned y) { return (x & 15u) > (y & 15u); });
           tmp = L;
           // only rounds whose 16 blocks of 64 are all complete are permuted
           const int fullRounds = (int)(L.size() / (size_t)(WAVES * 64));
-          for (int r = 1; r < fullRounds && T > 1; r += 2)
+          for (int r = 1; r < fullRounds && T > 1 && !getenv("PSBA_SCHUR_NOSORT"); r += 2)
             for (int w = 0; w < WAVES; w++) {
               const size_t src = (size_t)(r * WAVES + (WAVES - 1 - w)) * 64, dst = (size_t)(r * WAVES + w) * 64;
               std::copy(tmp.begin() + src, tmp.begin() + src + 64, L.begin() + dst);
