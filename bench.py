@@ -34,6 +34,26 @@ from psba_amd import capi, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the graded kernel from the newest committed rocprofv3 PMC passes
+    (profiles/*_profile.json, written by scripts/summarize_prof.py): 2 x FETCH_SIZE (the gfx950
+    correction for wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None when no profile of
+    this workload is committed (bench.py itself cannot collect PMC counters)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_profile.json"))):
+        try:
+            d = json.load(open(f))
+            if d["bench"]["config"]["workload"] != workload:
+                continue
+            for name, c in d["pmc_avg_per_launch_KiB"].items():
+                if "k_schur_lds" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    best = ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.basename(f))
+        except Exception:
+            continue
+    return best
+
+
 def load_workload(name, rank, nranks):
     data = os.path.join(ROOT, "tests", "golden", "data")
     if name == "venice-shaped":
@@ -173,6 +193,10 @@ def main():
                          "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
                          "traffic": None},
         }
+        tr = pmc_traffic(args.workload) if world == 1 else None
+        if tr:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/" + tr[1]
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_lib import Oracle  # the checker, timed as the CPU baseline ("port")
