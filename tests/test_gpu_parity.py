@@ -318,3 +318,40 @@ def test_two_rank_layout_emulated_on_one_gpu(problems):
     close(np.r_[c0.reshape(-1), p0.reshape(-1), p1.reshape(-1)], newp, 1e-9, "proposal")
     for h in hs + [ref]:
         h.close()
+
+
+def test_global_atomic_fallback_path(problems, monkeypatch):
+    """The K2 fallback used when S's block triangle cannot be split into <= 32 LDS-sized groups
+    (very many cameras) -- global fp64 atomics -- stays correct (forced with PSBA_SCHUR_ATOMIC)."""
+    import psba_amd
+    monkeypatch.setenv("PSBA_SCHUR_ATOMIC", "1")
+    prob = problems["54cams"]
+    o = Oracle(prob)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    close(h.compute_S(), sch["S"], 1e-11, "S")
+    close(h.compute_ea(), sch["eab"][: o.nA], 1e-10, "ea")
+    _, dp, _ = o.solve(lin, sch)
+    h.SPDinv_matVec()
+    close(h.compute_dpb(), dp, 1e-9, "dp")
+    h.close()
+
+
+def test_too_many_cameras_for_the_dense_solve_is_a_clean_error():
+    """6 nCams > 480 is beyond this round's single-workgroup Cholesky: the solve must say so
+    (PSBA_E_INVALID), not crash; assembly still works."""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=96, n_pts=400, mean_track=4.0, seed=5)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(1e3)
+    with pytest.raises(psba_amd.PsbaError):
+        h.schur_solve()
+    h.close()
