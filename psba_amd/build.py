@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpsba_hip.so")
 SOURCES = ["psba_api.cpp", "lm_loop.cpp", "sba_io.cpp", "kernels_linearize.hip",
-           "kernels_schur.hip", "kernels_chol.hip", "kernels_backsub.hip"]
+           "kernels_schur.hip", "kernels_chol.hip", "kernels_chol_graph.hip", "kernels_backsub.hip"]
 HEADERS = ["psba_internal.h", "camera_model.h", os.path.join("..", "..", "include", "psba_hip.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -23,6 +23,8 @@
 //      per row.
 // The backward solve L^T x = y is blocked the same way (substitution in one wave per block,
 // then a rank-32 update of the remaining right-hand side by all threads).
+#include <cstdlib>
+
 #include "psba_internal.h"
 
 namespace psba {
@@ -354,6 +356,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
 static bool g_chol_attr = false;
 
 int launch_chol_solve(psba_ctx *h) {
+  // default: the panel chain on the whole chip (kernels_chol_graph.hip); PSBA_CHOL_SINGLE=1
+  // selects this file's single-workgroup kernel
+  if (!getenv("PSBA_CHOL_SINGLE")) return launch_chol_graph(h);
   const Dims &d = h->d;
   const int n32 = h->n32;
   const int nTiles = n32 / 16 + 1;

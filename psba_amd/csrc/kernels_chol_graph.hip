@@ -1,0 +1,353 @@
+// kernels_chol_graph.hip -- the dense reduced-camera solve as a right-looking blocked Cholesky
+// spread over the whole chip: a short chain of small kernels per 32-column panel, captured
+// once into a hipGraph and replayed per damping try.
+//
+// Same job and same data as kernels_chol.hip (which stays as the single-workgroup fallback):
+// S dpa = ea on the padded reduce buffer Lw[(n32+16)][n32], e_a riding along as row n32 so that
+// the forward solve is free; replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
+// CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19).  The reference chains ~nA
+// device-enqueued launches of 3x3 blocks; here a panel is three steps:
+//   diag    one workgroup factors the 32x32 diagonal block (two 16-step factorizations with rows
+//           in registers + a 16x16 update) -- fused into the tail of the previous update;
+//   trsm    one thread per row below: X L_dd^T = C by forward substitution in two 16-wide halves;
+//   update  one wave per 16x16 tile of the trailing matrix: C -= X_r X_c^T with
+//           v_mfma_f64_16x16x4_f64 (K = 32), operands fetched as 64-byte pieces per lane.
+// A single workgroup (kernels_chol.hip) spends its time in ~100 dependent barrier phases and on
+// one CU's L2 port; here the bulk work runs on all CUs and only the diagonal factor is serial.
+// Kernel boundaries inside a graph cost ~1.5 us each.
+#include <cstdlib>
+
+#include "psba_internal.h"
+
+namespace psba {
+
+constexpr int GB = 32;  // panel width
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d16 __attribute__((ext_vector_type(16)));  // SSA vector: never demoted to scratch
+
+__device__ __forceinline__ double readlane_f64g(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// In-place Cholesky of the 16x16 block at sD[o..o+15][o..o+15] by one wave (lanes 0..15 hold
+// the rows in registers, the finished column is broadcast through sCol); sInv[o+c] = 1/L[c][c].
+// Returns true on a non-positive / non-finite pivot.
+__device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double *sCol, double *sInv, int o,
+                                         int lane) {
+  const int r = lane & 15;
+  d16 a;
+#pragma unroll
+  for (int c = 0; c < 16; c++) a[c] = sD[o + r][o + c];
+  bool bad = false;
+#pragma clang loop unroll(full)
+  for (int c = 0; c < 16; c++) {
+    const double d = readlane_f64g(a[c], c);
+    bad |= !(d > 0.0);
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * (1.5 - 0.5 * d * y * y);
+    y = y * (1.5 - 0.5 * d * y * y);
+    const double l = (r == c) ? d * y : a[c] * y;
+    a[c] = l;
+    if (lane == c) sInv[o + c] = y;
+    if (c + 1 < 16) {
+      sCol[r] = l;
+      __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(full)
+      for (int cc = c + 1; cc < 16; cc++) a[cc] -= l * sCol[cc];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) sD[o + r][o + c] = (c <= r) ? a[c] : 0.0;
+    if (!isfinite(a[r])) bad = true;
+  }
+  return bad;
+}
+
+// Factor the 32x32 block held in sD (lower triangle valid) with >= 128 threads of one workgroup:
+// factor D11; L21 = D21 L11^-T; D22 -= L21 L21^T; factor D22.  Uniform control flow.
+__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double *sCol, double *sInv,
+                                         int *sFail, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    if (factor16(sD, sCol, sInv, 0, lane)) *sFail = 1;
+  }
+  __syncthreads();
+  if (wave == 1 && lane < 16) {  // row 16 + lane of L21 by forward substitution
+    const int r = 16 + lane;
+    d16 x;
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = sD[r][c];
+#pragma clang loop unroll(full)
+    for (int c = 0; c < 16; c++) {
+      double v = x[c];
+#pragma clang loop unroll(full)
+      for (int k = 0; k < c; k++) v -= x[k] * sD[c][k];
+      x[c] = v * sInv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) sD[r][c] = x[c];
+  }
+  __syncthreads();
+  for (int t = tid; t < 256; t += blockDim.x) {  // D22 -= L21 L21^T (lower part)
+    const int r = t >> 4, c = t & 15;
+    if (c <= r) {
+      double v = sD[16 + r][16 + c];
+#pragma unroll
+      for (int k = 0; k < 16; k++) v -= sD[16 + r][k] * sD[16 + c][k];
+      sD[16 + r][16 + c] = v;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    if (factor16(sD, sCol, sInv, 16, lane)) *sFail = 1;
+  }
+  __syncthreads();
+}
+
+// diag: factor the block at (j, j) in place.  Launched alone only for the first panel.
+__global__ __launch_bounds__(128) void k_cholg_diag(double *Lw, int ld, int j, int *status) {
+  __shared__ double sD[GB][GB + 1];
+  __shared__ double sCol[16], sInv[GB];
+  __shared__ int sFail;
+  const int tid = threadIdx.x;
+  if (tid == 0) sFail = 0;
+  for (int t = tid; t < GB * GB; t += 128) sD[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
+  __syncthreads();
+  factor32(sD, sCol, sInv, &sFail, tid);
+  for (int t = tid; t < GB * GB; t += 128) {
+    const int r = t / GB, c = t % GB;
+    Lw[(size_t)(j + r) * ld + j + c] = (c <= r) ? sD[r][c] : 0.0;
+  }
+  if (tid == 0 && sFail) status[1] = status[3];  // status[3] = this try's stamp
+}
+
+// trsm: rows R in [j+32, rowEnd] (rowEnd = n32 = the e_a row): X L_dd^T = C, one thread per row.
+__global__ __launch_bounds__(64) void k_cholg_trsm(double *Lw, int ld, int j, int rowEnd) {
+  __shared__ double sL[GB][GB + 1];
+  __shared__ double sInv[GB];
+  const int tid = threadIdx.x;
+  for (int t = tid; t < GB * GB; t += 64) sL[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
+  __syncthreads();
+  if (tid < GB) sInv[tid] = 1.0 / sL[tid][tid];
+  __syncthreads();
+  const int R = j + GB + blockIdx.x * 64 + tid;
+  if (R > rowEnd) return;
+  double *row = Lw + (size_t)R * ld + j;
+  d16 x1, c2;
+  {
+    const double4 *src = reinterpret_cast<const double4 *>(row);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double4 a = src[q], b = src[4 + q];
+      x1[4 * q] = a.x; x1[4 * q + 1] = a.y; x1[4 * q + 2] = a.z; x1[4 * q + 3] = a.w;
+      c2[4 * q] = b.x; c2[4 * q + 1] = b.y; c2[4 * q + 2] = b.z; c2[4 * q + 3] = b.w;
+    }
+  }
+#pragma clang loop unroll(full)
+  for (int c = 0; c < 16; c++) {
+    double v = x1[c];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < c; k++) v -= x1[k] * sL[c][k];
+    x1[c] = v * sInv[c];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+  for (int c = 0; c < 16; c++) {
+    double v = c2[c];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 16; k++) v -= x1[k] * sL[16 + c][k];
+    c2[c] = v;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma clang loop unroll(full)
+  for (int c = 0; c < 16; c++) {
+    double v = c2[c];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < c; k++) v -= c2[k] * sL[16 + c][16 + k];
+    c2[c] = v * sInv[16 + c];
+  }
+  {
+    double4 *dst = reinterpret_cast<double4 *>(row);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      dst[q] = double4{x1[4 * q], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]};
+      dst[4 + q] = double4{c2[4 * q], c2[4 * q + 1], c2[4 * q + 2], c2[4 * q + 3]};
+    }
+  }
+}
+
+// one 16x16 tile of the trailing update: C[TR][TC] -= X[TR rows][j..j+31] X[TC rows][j..j+31]^T.
+// k-slot pairing: MFMA step t (0..7) pairs lane slot lk with column j + 8 lk + t, so each lane
+// fetches its eight operand values as one 64-byte piece of its row.
+__device__ __forceinline__ d4 update_tile(const double *Lw, int ld, int j, int TR, int TC, int li,
+                                          int lk) {
+  const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * TR + li) * ld + j + 8 * lk);
+  const double4 *bp = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * TC + li) * ld + j + 8 * lk);
+  const double4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
+  d4 c0, c1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; r++) c0[r] = Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li];
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.x, b0.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.y, b0.y, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.z, b0.z, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.w, b0.w, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.x, b1.x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.y, b1.y, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.z, b1.z, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.w, b1.w, c1, 0, 0, 0);
+  return c0 + c1;
+}
+
+// update: workgroup 0 owns the three tiles of the next diagonal block and factors it once they
+// are updated (the "diag" step of the next panel); every other workgroup owns four tiles
+// (one per wave) of the rest of the lower trailing triangle + the e_a tile row.
+__global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, int *status) {
+  __shared__ double sD[GB][GB + 1];
+  __shared__ double sCol[16], sInv[GB];
+  __shared__ int sFail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T0 = (j + GB) / 16;  // first trailing tile row / column
+  if (blockIdx.x == 0) {
+    if (tid == 0) sFail = 0;
+    if (wave < 3) {
+      const int TR = T0 + (wave > 0), TC = T0 + (wave > 1);
+      const d4 c = update_tile(Lw, ld, j, TR, TC, li, lk);
+#pragma unroll
+      for (int r = 0; r < 4; r++) sD[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
+    }
+    __syncthreads();
+    factor32(sD, sCol, sInv, &sFail, tid);
+    const int jn = j + GB;
+    for (int t = tid; t < GB * GB; t += 256) {
+      const int r = t / GB, c = t % GB;
+      Lw[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? sD[r][c] : 0.0;
+    }
+    if (tid == 0 && sFail) status[1] = status[3];
+    return;
+  }
+  // tiles: the lower triangle of the M x M trailing tile grid (row-major: local row m, index
+  // m (m + 1) / 2 + local column; the first three indices (0,0), (1,0), (1,1) belong to
+  // workgroup 0), followed by the M tiles of the e_a tile row (tile row nT - 1)
+  const long long idx = (long long)(blockIdx.x - 1) * 4 + wave + 3;
+  const long long M = (nT - 1) - T0;
+  const long long ntri = M * (M + 1) / 2;
+  if (idx >= ntri + M) return;
+  int TR, TC;
+  if (idx < ntri) {
+    int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+    while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+    while ((long long)m * (m + 1) / 2 > idx) m--;
+    TR = T0 + m;
+    TC = T0 + (int)(idx - (long long)m * (m + 1) / 2);
+  } else {
+    TR = nT - 1;
+    TC = T0 + (int)(idx - ntri);
+  }
+  const d4 c = update_tile(Lw, ld, j, TR, TC, li, lk);
+#pragma unroll
+  for (int r = 0; r < 4; r++) Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li] = c[r];
+}
+
+// backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 16:
+// one wave solves the diagonal block by substitution, then all threads apply
+// y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update are fetched before the
+// substitution starts (first chunk of columns) so that their latency overlaps it.
+__global__ __launch_bounds__(1024) void k_cholg_backward(double *Lw, int ld, int n, int n32, double *x,
+                                                        int *status) {
+  __shared__ double sX[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  double *y = Lw + (size_t)n32 * ld;
+  for (int j = n32 - 16; j >= 0; j -= 16) {
+    double lcur[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) lcur[r] = (tid < j) ? Lw[(size_t)(j + r) * ld + tid] : 0.0;
+    if (wave == 0) {
+      const int r = lane & 15;
+      d16 lcol;
+#pragma unroll
+      for (int k = 0; k < 16; k++) lcol[k] = Lw[(size_t)(j + k) * ld + j + r];  // L_dd[k][r]
+      double z = y[j + r];
+#pragma clang loop unroll(full)
+      for (int k = 15; k >= 0; k--) {
+        const double xk = readlane_f64g(z, k) / readlane_f64g(lcol[k], k);
+        if (r == k) z = xk;
+        if (r < k) z -= lcol[k] * xk;
+      }
+      if (lane < 16) {
+        sX[r] = z;
+        if (j + r < n) x[j + r] = z;
+      }
+    }
+    __syncthreads();
+    if (tid < j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc += lcur[r] * sX[r];
+      y[tid] -= acc;
+    }
+    for (int c = tid + nthr; c < j; c += nthr) {  // only when n32 > blockDim.x
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc += Lw[(size_t)(j + r) * ld + c] * sX[r];
+      y[c] -= acc;
+    }
+    __syncthreads();
+  }
+  int bad = 0;
+  for (int t = tid; t < n; t += nthr)
+    if (!isfinite(x[t])) bad = 1;
+  if (bad) status[1] = status[3];
+}
+
+static void enqueue_chain(psba_ctx *h, hipStream_t s) {
+  const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
+  double *Lw = h->red;
+  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(128), 0, s, Lw, ld, 0, h->status);
+  for (int j = 0; j < n32; j += GB) {
+    const int rows = n32 - (j + GB) + 1;  // rows below the panel incl. the e_a row
+    hipLaunchKernelGGL(k_cholg_trsm, dim3((rows + 63) / 64), dim3(64), 0, s, Lw, ld, j, n32);
+    if (j + GB < n32) {
+      const long long M = (nT - 1) - (j + GB) / 16;
+      const long long tiles = M * (M + 1) / 2 + M - 3;
+      const int grid = 1 + (int)((tiles + 3) / 4);
+      hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, ld, j, nT, h->status);
+    }
+  }
+  int thr = (n32 + 63) / 64 * 64;
+  if (thr > 1024) thr = 1024;
+  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lw, ld, h->d.nA, n32, h->dp, h->status);
+}
+
+int launch_chol_graph(psba_ctx *h) {
+  if (!h->chol_graph || h->chol_graph_n32 != h->n32 || h->chol_graph_red != h->red) {
+    if (h->chol_graph) {
+      (void)hipGraphExecDestroy(h->chol_graph);
+      h->chol_graph = nullptr;
+    }
+    hipGraph_t g = nullptr;
+    PSBA_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_chain(h, h->stream);
+    PSBA_HIP(h, hipStreamEndCapture(h->stream, &g));
+    hipError_t e = hipGraphInstantiate(&h->chol_graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+      h->chol_graph = nullptr;
+      return fail(h, PSBA_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    h->chol_graph_n32 = h->n32;
+    h->chol_graph_red = h->red;
+  }
+  {
+    ProfScope ps(h, PSBA_K_CHOLESKY);
+    PSBA_HIP(h, hipGraphLaunch(h->chol_graph, h->stream));
+  }
+  return PSBA_OK;
+}
+
+}  // namespace psba

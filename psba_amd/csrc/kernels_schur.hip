@@ -284,10 +284,13 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nC
                                                       unsigned long long packedN, const double *U,
                                                       const double *ga, double mu_add, int nA,
                                                       int n32, double pad_one, double *S,
-                                                      double *ea, double *scal) {
+                                                      double *ea, double *scal, int *status,
+                                                      int try_id) {
   __shared__ double sAcc[4][64];
-  // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2)
+  // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
+  // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
   if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 4) status[3] = try_id;
   write_padding(S, nA, n32, pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                 (size_t)gridDim.x * blockDim.x);
   const unsigned long long total = packedN + nA;
@@ -337,8 +340,10 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nC
 // of the per-rank contributions adds mu exactly once.
 __global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, const double *U,
                                                         const double *ga, double mu_add, int nA,
-                                                        int n32, double pad_one, double *scal) {
+                                                        int n32, double pad_one, double *scal,
+                                                        int *status, int try_id) {
   if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 4) status[3] = try_id;
   const size_t n2 = (size_t)nA * nA;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t gsize = (size_t)gridDim.x * blockDim.x;
@@ -413,7 +418,8 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
     ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
     hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, h->slab, h->nChunks,
                        a.slabStride, a.packedN, h->U, h->ga, mu_add, d.nA, h->n32,
-                       h->rank == 0 ? 1.0 : 0.0, h->red, h->red + (size_t)h->n32 * h->n32, h->scal);
+                       h->rank == 0 ? 1.0 : 0.0, h->red, h->red + (size_t)h->n32 * h->n32, h->scal, h->status,
+                       h->try_id);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
@@ -470,7 +476,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   int fgrid = (int)((n2 + 255) / 256);
   if (fgrid > 1024) fgrid = 1024;
   hipLaunchKernelGGL(k_schur_finalize, dim3(fgrid), dim3(256), 0, h->stream, a.S, a.ea, h->U, h->ga,
-                     mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0, h->scal);
+                     mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0, h->scal, h->status, h->try_id);
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
 }

@@ -82,6 +82,10 @@ static void dev_free(T *&p) {
 }
 
 static void free_problem_buffers(psba_ctx *h) {
+  if (h->chol_graph) {
+    (void)hipGraphExecDestroy(h->chol_graph);
+    h->chol_graph = nullptr;
+  }
   dev_free(h->camconst);
   dev_free(h->cams[0]);
   dev_free(h->cams[1]);

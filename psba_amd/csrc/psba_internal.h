@@ -76,11 +76,15 @@ struct psba_ctx {
   double *slab = nullptr;       // [nChunks][packedN + nA] per-chunk partial -sum(Y W^T) | -sum(Y g_b)
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
+  hipGraphExec_t chol_graph = nullptr;  // captured panel chain of kernels_chol_graph.hip
+  int chol_graph_n32 = 0;
+  double *chol_graph_red = nullptr;
   long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
   double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
   double *scal = nullptr;       // [NSCAL]
   // [4] generation stamps, never zeroed: [0] == try_id <=> some V_i singular in this try,
-  // [1] == try_id <=> the Cholesky of this try failed.  Lives in scal[8..9]
+  // [1] == try_id <=> the Cholesky of this try failed; [3] = try_id as seen by the graph-replayed
+  // Cholesky kernels (written by the K2 reduce kernel).  Lives in scal[8..9]
   int *status = nullptr;
   int try_id = 0;
   double *h_scal = nullptr;     // pinned mirror of scal
@@ -132,6 +136,8 @@ int launch_max_diag(psba_ctx *h);
 int launch_schur(psba_ctx *h, double mu, bool dump);
 // kernels_chol.hip
 int launch_chol_solve(psba_ctx *h);
+// kernels_chol_graph.hip
+int launch_chol_graph(psba_ctx *h);
 // kernels_backsub.hip
 int launch_backsub(psba_ctx *h, double mu, bool dump);
 

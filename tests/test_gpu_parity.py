@@ -342,16 +342,47 @@ def test_global_atomic_fallback_path(problems, monkeypatch):
     h.close()
 
 
-def test_too_many_cameras_for_the_dense_solve_is_a_clean_error():
-    """6 nCams > 480 is beyond this round's single-workgroup Cholesky: the solve must say so
-    (PSBA_E_INVALID), not crash; assembly still works."""
-    import psba_amd
+def test_many_cameras(gpu):
+    """96 cameras (nA = 576: beyond the single-workgroup Cholesky of kernels_chol.hip, 5 LDS
+    groups in K2): the panel-chain solve has no such limit."""
     import psba_amd.synth as synth
-    prob = synth.make_problem(n_cams=96, n_pts=400, mean_track=4.0, seed=5)
+    prob = synth.make_problem(n_cams=96, n_pts=3000, mean_track=5.0, seed=5)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    gpu.linearize(1.0, 1.0)
+    gpu.update_UV(mu)
+    close(gpu.compute_S(), sch["S"], 1e-11, "S")
+    ret, dp, _ = o.solve(lin, sch)
+    rc, dpa = gpu.SPDinv_matVec()
+    assert rc == 0 and ret == 0.0
+    close(dpa, dp[: o.nA], 1e-8, "dpa")
+    close(gpu.compute_dpb(), dp, 1e-8, "dp")
+    gpu.restore_UVdiag()
+    gpu.upload_problem(prob)
+    res, _ = gpu.levmar(max_iter=6, tr_handoff=False)
+    ores, _ = Oracle(prob).levmar(max_iter=6, tr_handoff=False)
+    assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
+
+
+def test_single_workgroup_cholesky_fallback(problems, monkeypatch):
+    """PSBA_CHOL_SINGLE=1 selects the one-workgroup kernel of kernels_chol.hip; it must agree."""
+    import psba_amd
+    monkeypatch.setenv("PSBA_CHOL_SINGLE", "1")
+    prob = problems["54cams"]
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, _ = o.solve(lin, sch)
     h = psba_amd.Psba(0)
     h.upload_problem(prob)
     h.linearize(1.0, 1.0)
-    h.schur_assemble(1e3)
-    with pytest.raises(psba_amd.PsbaError):
-        h.schur_solve()
+    h.update_UV(mu)
+    h.compute_S()
+    rc, dpa = h.SPDinv_matVec()
+    assert rc == 0
+    close(dpa, dp[: o.nA], 1e-9, "dpa")
     h.close()
