@@ -8,8 +8,9 @@
 // CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19).  The reference chains ~nA
 // device-enqueued launches of 3x3 blocks; here a panel is three steps:
 //   diag    one workgroup factors the 32x32 diagonal block (two 16-step factorizations with rows
-//           in registers + a 16x16 update) -- fused into the tail of the previous update;
-//   trsm    one thread per row below: X L_dd^T = C by forward substitution in two 16-wide halves;
+//           in registers + a 16x16 update) and inverts the factor -- fused into the tail of the
+//           previous update;
+//   trsm    one wave per 16-row tile below: X = C L_dd^-T as a 16x32x32 MFMA product;
 //   update  one wave per 16x16 tile of the trailing matrix: C -= X_r X_c^T with
 //           v_mfma_f64_16x16x4_f64 (K = 32), operands fetched as 64-byte pieces per lane.
 // A single workgroup (kernels_chol.hip) spends its time in ~100 dependent barrier phases and on
@@ -68,10 +69,30 @@ __device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double *sCol, dou
   return bad;
 }
 
-// Factor the 32x32 block held in sD (lower triangle valid) with >= 128 threads of one workgroup:
-// factor D11; L21 = D21 L11^-T; D22 -= L21 L21^T; factor D22.  Uniform control flow.
-__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double *sCol, double *sInv,
-                                         int *sFail, int tid) {
+// inverse of the 16x16 lower-triangular block at sD[o..][o..] into sLi[o..][o..]: lane c < 16
+// computes column c by forward substitution (column in registers, L from LDS).
+__device__ __forceinline__ void invert16(double (*sD)[GB + 1], double (*sLi)[GB + 1], const double *sInv,
+                                         int o, int lane) {
+  if (lane >= 16) return;
+  const int c = lane;
+  d16 x;
+#pragma clang loop unroll(full)
+  for (int r = 0; r < 16; r++) {
+    double v = (r == c) ? 1.0 : 0.0;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < r; k++) v -= sD[o + r][o + k] * x[k];
+    x[r] = (r < c) ? 0.0 : v * sInv[o + r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) sLi[o + r][o + c] = x[r];
+}
+
+// Factor the 32x32 block held in sD (lower triangle valid) and invert the factor into sLi, with
+// >= 192 threads of one workgroup: factor D11; [L21 = D21 L11^-T  ||  inv(L11)];
+// D22 -= L21 L21^T; factor D22; inv(L22); Li21 = -inv(L22) L21 inv(L11).  Uniform control flow.
+__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB + 1], double *sCol,
+                                         double *sInv, int *sFail, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   if (wave == 0) {
     if (factor16(sD, sCol, sInv, 0, lane)) *sFail = 1;
@@ -92,6 +113,7 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double *sCol, dou
 #pragma unroll
     for (int c = 0; c < 16; c++) sD[r][c] = x[c];
   }
+  if (wave == 2) invert16(sD, sLi, sInv, 0, lane);
   __syncthreads();
   for (int t = tid; t < 256; t += blockDim.x) {  // D22 -= L21 L21^T (lower part)
     const int r = t >> 4, c = t & 15;
@@ -107,77 +129,90 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double *sCol, dou
     if (factor16(sD, sCol, sInv, 16, lane)) *sFail = 1;
   }
   __syncthreads();
+  if (wave == 0) invert16(sD, sLi, sInv, 16, lane);
+  // T = L21 inv(L11) into the (unused) upper-right quadrant of sLi
+  for (int t = tid; t < 256; t += blockDim.x) {
+    const int r = t >> 4, c = t & 15;
+    double v = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; m++) v += sD[16 + r][m] * sLi[m][c];  // inv(L11) is lower: zeros above
+    sLi[r][16 + c] = v;
+  }
+  __syncthreads();
+  double li21[(256 + 191) / 192];
+  int q = 0;
+  for (int t = tid; t < 256; t += blockDim.x, q++) {
+    const int r = t >> 4, c = t & 15;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v -= sLi[16 + r][16 + k] * sLi[k][16 + c];
+    li21[q] = v;
+  }
+  __syncthreads();
+  q = 0;
+  for (int t = tid; t < 256; t += blockDim.x, q++) {
+    const int r = t >> 4, c = t & 15;
+    sLi[16 + r][c] = li21[q];
+    sLi[r][16 + c] = 0.0;
+  }
+  __syncthreads();
 }
 
-// diag: factor the block at (j, j) in place.  Launched alone only for the first panel.
-__global__ __launch_bounds__(128) void k_cholg_diag(double *Lw, int ld, int j, int *status) {
-  __shared__ double sD[GB][GB + 1];
+// diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
+// alone only for the first panel.
+__global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status) {
+  __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
   __shared__ double sCol[16], sInv[GB];
   __shared__ int sFail;
   const int tid = threadIdx.x;
   if (tid == 0) sFail = 0;
-  for (int t = tid; t < GB * GB; t += 128) sD[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
+  for (int t = tid; t < GB * GB; t += 256) sD[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
   __syncthreads();
-  factor32(sD, sCol, sInv, &sFail, tid);
-  for (int t = tid; t < GB * GB; t += 128) {
+  factor32(sD, sLi, sCol, sInv, &sFail, tid);
+  double *li = linv + (size_t)(j / GB) * GB * GB;
+  for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
     Lw[(size_t)(j + r) * ld + j + c] = (c <= r) ? sD[r][c] : 0.0;
+    li[t] = (c <= r) ? sLi[r][c] : 0.0;
   }
   if (tid == 0 && sFail) status[1] = status[3];  // status[3] = this try's stamp
 }
 
-// trsm: rows R in [j+32, rowEnd] (rowEnd = n32 = the e_a row): X L_dd^T = C, one thread per row.
-__global__ __launch_bounds__(64) void k_cholg_trsm(double *Lw, int ld, int j, int rowEnd) {
-  __shared__ double sL[GB][GB + 1];
-  __shared__ double sInv[GB];
-  const int tid = threadIdx.x;
-  for (int t = tid; t < GB * GB; t += 64) sL[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
-  __syncthreads();
-  if (tid < GB) sInv[tid] = 1.0 / sL[tid][tid];
-  __syncthreads();
-  const int R = j + GB + blockIdx.x * 64 + tid;
-  if (R > rowEnd) return;
-  double *row = Lw + (size_t)R * ld + j;
-  d16 x1, c2;
-  {
-    const double4 *src = reinterpret_cast<const double4 *>(row);
+// trsm: X = C L_dd^-T for the 16-row tiles below the panel's diagonal block (incl. the e_a tile),
+// one wave per tile: a 16x32x32 product with the stored inverse, 16 MFMAs.  k-slot pairing: MFMA
+// step t (0..7) pairs lane slot lk with k = 8 lk + t, so each lane fetches its operand values as
+// one 64-byte piece of its row (of C, and of L_dd^-1 whose rows are the columns of L_dd^-T).
+__global__ __launch_bounds__(256) void k_cholg_trsm(double *Lw, int ld, int j, int nT, const double *linv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T = (j + GB) / 16 + blockIdx.x * 4 + wave;
+  if (T >= nT) return;
+  const double *Li = linv + (size_t)(j / GB) * GB * GB;
+  const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * T + li) * ld + j + 8 * lk);
+  const double4 *b0p = reinterpret_cast<const double4 *>(Li + (size_t)li * GB + 8 * lk);
+  const double4 *b1p = reinterpret_cast<const double4 *>(Li + (size_t)(16 + li) * GB + 8 * lk);
+  const double4 a0 = ap[0], a1 = ap[1], p0 = b0p[0], p1 = b0p[1], q0 = b1p[0], q1 = b1p[1];
+  d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+  x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, p0.x, x0, 0, 0, 0);
+  y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, q0.x, y0, 0, 0, 0);
+  x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, p0.y, x1, 0, 0, 0);
+  y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, q0.y, y1, 0, 0, 0);
+  x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.z, p0.z, x0, 0, 0, 0);
+  y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.z, q0.z, y0, 0, 0, 0);
+  x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.w, p0.w, x1, 0, 0, 0);
+  y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.w, q0.w, y1, 0, 0, 0);
+  x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, p1.x, x0, 0, 0, 0);
+  y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, q1.x, y0, 0, 0, 0);
+  x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, p1.y, x1, 0, 0, 0);
+  y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, q1.y, y1, 0, 0, 0);
+  x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.z, p1.z, x0, 0, 0, 0);
+  y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.z, q1.z, y0, 0, 0, 0);
+  x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.w, p1.w, x1, 0, 0, 0);
+  y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.w, q1.w, y1, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const double4 a = src[q], b = src[4 + q];
-      x1[4 * q] = a.x; x1[4 * q + 1] = a.y; x1[4 * q + 2] = a.z; x1[4 * q + 3] = a.w;
-      c2[4 * q] = b.x; c2[4 * q + 1] = b.y; c2[4 * q + 2] = b.z; c2[4 * q + 3] = b.w;
-    }
-  }
-#pragma clang loop unroll(full)
-  for (int c = 0; c < 16; c++) {
-    double v = x1[c];
-#pragma clang loop unroll(full)
-    for (int k = 0; k < c; k++) v -= x1[k] * sL[c][k];
-    x1[c] = v * sInv[c];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma clang loop unroll(full)
-  for (int c = 0; c < 16; c++) {
-    double v = c2[c];
-#pragma clang loop unroll(full)
-    for (int k = 0; k < 16; k++) v -= x1[k] * sL[16 + c][k];
-    c2[c] = v;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma clang loop unroll(full)
-  for (int c = 0; c < 16; c++) {
-    double v = c2[c];
-#pragma clang loop unroll(full)
-    for (int k = 0; k < c; k++) v -= c2[k] * sL[16 + c][16 + k];
-    c2[c] = v * sInv[16 + c];
-  }
-  {
-    double4 *dst = reinterpret_cast<double4 *>(row);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      dst[q] = double4{x1[4 * q], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]};
-      dst[4 + q] = double4{c2[4 * q], c2[4 * q + 1], c2[4 * q + 2], c2[4 * q + 3]};
-    }
+  for (int r = 0; r < 4; r++) {
+    Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li] = x0[r] + x1[r];
+    Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 + li] = y0[r] + y1[r];
   }
 }
 
@@ -206,8 +241,9 @@ __device__ __forceinline__ d4 update_tile(const double *Lw, int ld, int j, int T
 // update: workgroup 0 owns the three tiles of the next diagonal block and factors it once they
 // are updated (the "diag" step of the next panel); every other workgroup owns four tiles
 // (one per wave) of the rest of the lower trailing triangle + the e_a tile row.
-__global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, int *status) {
-  __shared__ double sD[GB][GB + 1];
+__global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, double *linv,
+                                                      int *status) {
+  __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
   __shared__ double sCol[16], sInv[GB];
   __shared__ int sFail;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,11 +258,13 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j,
       for (int r = 0; r < 4; r++) sD[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
     }
     __syncthreads();
-    factor32(sD, sCol, sInv, &sFail, tid);
+    factor32(sD, sLi, sCol, sInv, &sFail, tid);
     const int jn = j + GB;
+    double *li = linv + (size_t)(jn / GB) * GB * GB;
     for (int t = tid; t < GB * GB; t += 256) {
       const int r = t / GB, c = t % GB;
       Lw[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? sD[r][c] : 0.0;
+      li[t] = (c <= r) ? sLi[r][c] : 0.0;
     }
     if (tid == 0 && sFail) status[1] = status[3];
     return;
@@ -254,47 +292,45 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j,
   for (int r = 0; r < 4; r++) Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li] = c[r];
 }
 
-// backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 16:
-// one wave solves the diagonal block by substitution, then all threads apply
-// y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update are fetched before the
-// substitution starts (first chunk of columns) so that their latency overlaps it.
+// backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 32:
+// x_J = L_dd^-T y_J is a 32x32 mat-vec with the stored inverse (no dependent chain), then all
+// threads apply y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update do not depend on x
+// and are fetched before the mat-vec so that their latency overlaps it.
 __global__ __launch_bounds__(1024) void k_cholg_backward(double *Lw, int ld, int n, int n32, double *x,
-                                                        int *status) {
-  __shared__ double sX[16];
+                                                        const double *linv, int *status) {
+  __shared__ double sX[GB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   double *y = Lw + (size_t)n32 * ld;
-  for (int j = n32 - 16; j >= 0; j -= 16) {
-    double lcur[16];
+  for (int j = n32 - GB; j >= 0; j -= GB) {
+    double lcur[GB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) lcur[r] = (tid < j) ? Lw[(size_t)(j + r) * ld + tid] : 0.0;
+    for (int r = 0; r < GB; r++) lcur[r] = (tid < j) ? Lw[(size_t)(j + r) * ld + tid] : 0.0;
     if (wave == 0) {
-      const int r = lane & 15;
-      d16 lcol;
+      const double *Li = linv + (size_t)(j / GB) * GB * GB;
+      const int c = lane & (GB - 1), half = lane >> 5;
+      double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) lcol[k] = Lw[(size_t)(j + k) * ld + j + r];  // L_dd[k][r]
-      double z = y[j + r];
-#pragma clang loop unroll(full)
-      for (int k = 15; k >= 0; k--) {
-        const double xk = readlane_f64g(z, k) / readlane_f64g(lcol[k], k);
-        if (r == k) z = xk;
-        if (r < k) z -= lcol[k] * xk;
+      for (int rr = 0; rr < GB / 2; rr++) {
+        const int r = 2 * rr + half;
+        acc += Li[r * GB + c] * y[j + r];  // (L_dd^-T y)[c] = sum_r Linv[r][c] y[r]; zeros for r < c
       }
-      if (lane < 16) {
-        sX[r] = z;
-        if (j + r < n) x[j + r] = z;
+      acc += __shfl_xor(acc, 32, 64);
+      if (lane < GB) {
+        sX[c] = acc;
+        if (j + c < n) x[j + c] = acc;
       }
     }
     __syncthreads();
     if (tid < j) {
       double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc += lcur[r] * sX[r];
+      for (int r = 0; r < GB; r++) acc += lcur[r] * sX[r];
       y[tid] -= acc;
     }
     for (int c = tid + nthr; c < j; c += nthr) {  // only when n32 > blockDim.x
       double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc += Lw[(size_t)(j + r) * ld + c] * sX[r];
+      for (int r = 0; r < GB; r++) acc += Lw[(size_t)(j + r) * ld + c] * sX[r];
       y[c] -= acc;
     }
     __syncthreads();
@@ -307,21 +343,22 @@ __global__ __launch_bounds__(1024) void k_cholg_backward(double *Lw, int ld, int
 
 static void enqueue_chain(psba_ctx *h, hipStream_t s) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
-  double *Lw = h->red;
-  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(128), 0, s, Lw, ld, 0, h->status);
+  double *Lw = h->red, *linv = h->chol_ws;
+  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, ld, 0, linv, h->status);
   for (int j = 0; j < n32; j += GB) {
-    const int rows = n32 - (j + GB) + 1;  // rows below the panel incl. the e_a row
-    hipLaunchKernelGGL(k_cholg_trsm, dim3((rows + 63) / 64), dim3(64), 0, s, Lw, ld, j, n32);
+    const int tilesBelow = nT - (j + GB) / 16;  // 16-row tiles below the panel incl. the e_a tile
+    hipLaunchKernelGGL(k_cholg_trsm, dim3((tilesBelow + 3) / 4), dim3(256), 0, s, Lw, ld, j, nT, linv);
     if (j + GB < n32) {
       const long long M = (nT - 1) - (j + GB) / 16;
       const long long tiles = M * (M + 1) / 2 + M - 3;
       const int grid = 1 + (int)((tiles + 3) / 4);
-      hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, ld, j, nT, h->status);
+      hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, ld, j, nT, linv, h->status);
     }
   }
   int thr = (n32 + 63) / 64 * 64;
   if (thr > 1024) thr = 1024;
-  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lw, ld, h->d.nA, n32, h->dp, h->status);
+  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lw, ld, h->d.nA, n32, h->dp, linv,
+                     h->status);
 }
 
 int launch_chol_graph(psba_ctx *h) {
