@@ -33,32 +33,42 @@ __device__ __forceinline__ double readlane_f64g(double v, int srclane) {
 }
 
 // In-place Cholesky of the 16x16 block at sD[o..o+15][o..o+15] by one wave (lanes 0..15 hold
-// the rows in registers, the finished column is broadcast through sCol); sInv[o+c] = 1/L[c][c].
-// Returns true on a non-positive / non-finite pivot.
-__device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double *sCol, double *sInv, int o,
+// the rows in registers); sInv[o+c] = 1/L[c][c].  Returns true on a non-positive / non-finite
+// pivot.  The dependent chain per column is kept short: the next pivot only needs column c's
+// contribution to the next row's diagonal entry, which travels by v_readlane; the rest of
+// column c is broadcast through LDS (sCol, double-buffered) and applied one step later, when
+// its round trip has long finished behind the next column's rsq / Newton chain.
+__device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double (*sCol)[16], double *sInv, int o,
                                          int lane) {
   const int r = lane & 15;
   d16 a;
 #pragma unroll
   for (int c = 0; c < 16; c++) a[c] = sD[o + r][o + c];
   bool bad = false;
+  double d = readlane_f64g(a[0], 0);
+  double lprev = 0.0;
 #pragma clang loop unroll(full)
   for (int c = 0; c < 16; c++) {
-    const double d = readlane_f64g(a[c], c);
     bad |= !(d > 0.0);
     double y = __builtin_amdgcn_rsq(d);
     y = y * (1.5 - 0.5 * d * y * y);
     y = y * (1.5 - 0.5 * d * y * y);
-    const double l = (r == c) ? d * y : a[c] * y;
+    const double l = (r == c) ? d * y : a[c] * y;  // L[c][c] = sqrt(d), L[r][c] = a / sqrt(d)
     a[c] = l;
     if (lane == c) sInv[o + c] = y;
     if (c + 1 < 16) {
-      sCol[r] = l;
-      __builtin_amdgcn_wave_barrier();
+      sCol[c & 1][r] = l;
+      // next row's entry first: column c-1 (LDS, written a step ago) and column c (readlane)
+      if (c > 0) a[c + 1] -= lprev * sCol[(c - 1) & 1][c + 1];
+      a[c + 1] -= l * readlane_f64g(l, c + 1);
+      d = readlane_f64g(a[c + 1], c + 1);
+      // then the rest of column c-1, off the pivot chain
+      if (c > 0) {
 #pragma clang loop unroll(full)
-      for (int cc = c + 1; cc < 16; cc++) a[cc] -= l * sCol[cc];
+        for (int cc = c + 2; cc < 16; cc++) a[cc] -= lprev * sCol[(c - 1) & 1][cc];
+      }
+      lprev = l;
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (lane < 16) {
@@ -91,8 +101,8 @@ __device__ __forceinline__ void invert16(double (*sD)[GB + 1], double (*sLi)[GB 
 // Factor the 32x32 block held in sD (lower triangle valid) and invert the factor into sLi, with
 // >= 192 threads of one workgroup: factor D11; [L21 = D21 L11^-T  ||  inv(L11)];
 // D22 -= L21 L21^T; factor D22; inv(L22); Li21 = -inv(L22) L21 inv(L11).  Uniform control flow.
-__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB + 1], double *sCol,
-                                         double *sInv, int *sFail, int tid) {
+__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB + 1],
+                                         double (*sCol)[16], double *sInv, int *sFail, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   if (wave == 0) {
     if (factor16(sD, sCol, sInv, 0, lane)) *sFail = 1;
@@ -162,7 +172,7 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB 
 // alone only for the first panel.
 __global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status) {
   __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
-  __shared__ double sCol[16], sInv[GB];
+  __shared__ double sCol[2][16], sInv[GB];
   __shared__ int sFail;
   const int tid = threadIdx.x;
   if (tid == 0) sFail = 0;
@@ -244,7 +254,7 @@ __device__ __forceinline__ d4 update_tile(const double *Lw, int ld, int j, int T
 __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, double *linv,
                                                       int *status) {
   __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
-  __shared__ double sCol[16], sInv[GB];
+  __shared__ double sCol[2][16], sInv[GB];
   __shared__ int sFail;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -296,28 +306,46 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j,
 // x_J = L_dd^-T y_J is a 32x32 mat-vec with the stored inverse (no dependent chain), then all
 // threads apply y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update do not depend on x
 // and are fetched before the mat-vec so that their latency overlaps it.
-__global__ __launch_bounds__(1024) void k_cholg_backward(double *Lw, int ld, int n, int n32, double *x,
-                                                        const double *linv, int *status) {
+__global__ __launch_bounds__(512) void k_cholg_backward(double *Lw, int ld, int n, int n32, double *x,
+                                                       const double *linv, int *status) {
   __shared__ double sX[GB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   double *y = Lw + (size_t)n32 * ld;
-  for (int j = n32 - GB; j >= 0; j -= GB) {
-    double lcur[GB];
+  // operands of block J-1 (its rows of L for the y update, its inverse for the mat-vec) are
+  // fetched while block J is processed: none of them depends on x
+  double lnext[GB], inext[GB / 2];
+  const int c0 = lane & (GB - 1), half = lane >> 5;
+  {
+    const int j = n32 - GB;
 #pragma unroll
-    for (int r = 0; r < GB; r++) lcur[r] = (tid < j) ? Lw[(size_t)(j + r) * ld + tid] : 0.0;
+    for (int r = 0; r < GB; r++) lnext[r] = (tid < j) ? Lw[(size_t)(j + r) * ld + tid] : 0.0;
+    const double *Li = linv + (size_t)(j / GB) * GB * GB;
+#pragma unroll
+    for (int rr = 0; rr < GB / 2; rr++) inext[rr] = (wave == 0) ? Li[(2 * rr + half) * GB + c0] : 0.0;
+  }
+  for (int j = n32 - GB; j >= 0; j -= GB) {
+    double lcur[GB], icur[GB / 2];
+#pragma unroll
+    for (int r = 0; r < GB; r++) lcur[r] = lnext[r];
+#pragma unroll
+    for (int rr = 0; rr < GB / 2; rr++) icur[rr] = inext[rr];
+    if (j >= GB) {
+      const int jn = j - GB;
+#pragma unroll
+      for (int r = 0; r < GB; r++) lnext[r] = (tid < jn) ? Lw[(size_t)(jn + r) * ld + tid] : 0.0;
+      const double *Li = linv + (size_t)(jn / GB) * GB * GB;
+#pragma unroll
+      for (int rr = 0; rr < GB / 2; rr++) inext[rr] = (wave == 0) ? Li[(2 * rr + half) * GB + c0] : 0.0;
+    }
     if (wave == 0) {
-      const double *Li = linv + (size_t)(j / GB) * GB * GB;
-      const int c = lane & (GB - 1), half = lane >> 5;
       double acc = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < GB / 2; rr++) {
-        const int r = 2 * rr + half;
-        acc += Li[r * GB + c] * y[j + r];  // (L_dd^-T y)[c] = sum_r Linv[r][c] y[r]; zeros for r < c
-      }
+      for (int rr = 0; rr < GB / 2; rr++)
+        acc += icur[rr] * y[j + 2 * rr + half];  // (L_dd^-T y)[c] = sum_r Linv[r][c] y[r]
       acc += __shfl_xor(acc, 32, 64);
       if (lane < GB) {
-        sX[c] = acc;
-        if (j + c < n) x[j + c] = acc;
+        sX[c0] = acc;
+        if (j + c0 < n) x[j + c0] = acc;
       }
     }
     __syncthreads();
@@ -356,7 +384,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s) {
     }
   }
   int thr = (n32 + 63) / 64 * 64;
-  if (thr > 1024) thr = 1024;
+  if (thr > 512) thr = 512;
   hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lw, ld, h->d.nA, n32, h->dp, linv,
                      h->status);
 }
