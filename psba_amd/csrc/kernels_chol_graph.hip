@@ -34,10 +34,13 @@ __device__ __forceinline__ double readlane_f64g(double v, int srclane) {
 
 // In-place Cholesky of the 16x16 block at sD[o..o+15][o..o+15] by one wave (lanes 0..15 hold
 // the rows in registers); sInv[o+c] = 1/L[c][c].  Returns true on a non-positive / non-finite
-// pivot.  The dependent chain per column is kept short: the next pivot only needs column c's
-// contribution to the next row's diagonal entry, which travels by v_readlane; the rest of
-// column c is broadcast through LDS (sCol, double-buffered) and applied one step later, when
-// its round trip has long finished behind the next column's rsq / Newton chain.
+// pivot.  The dependent chain per column is kept to rsq + two Newton steps + one v_readlane:
+//  * the finished column c is broadcast through LDS (sCol, double-buffered) and consumed one
+//    step later; its reads are issued at the top of the next step, ahead of the rsq chain;
+//  * the next pivot needs column c only through the next row's own entry (l * l in the diagonal
+//    lane), so no cross-lane traffic sits between two pivots except the readlane of the pivot.
+// Invariant at the top of step c: a[c] holds columns < c-1 for every lane, column c-1 only in
+// the diagonal lane (r == c), and d = the finished pivot a[c][c] is known to all lanes.
 __device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double (*sCol)[16], double *sInv, int o,
                                          int lane) {
   const int r = lane & 15;
@@ -49,27 +52,31 @@ __device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double (*sCol)[16
   double lprev = 0.0;
 #pragma clang loop unroll(full)
   for (int c = 0; c < 16; c++) {
+    d16 v;  // column c-1 of L as broadcast by its owners (entries c..15 used)
+    if (c > 0) {
+#pragma clang loop unroll(full)
+      for (int cc = c; cc < 16; cc++) v[cc] = sCol[(c - 1) & 1][cc];
+    }
     bad |= !(d > 0.0);
     double y = __builtin_amdgcn_rsq(d);
     y = y * (1.5 - 0.5 * d * y * y);
     y = y * (1.5 - 0.5 * d * y * y);
+    if (c > 0 && r != c) a[c] -= lprev * v[c];
     const double l = (r == c) ? d * y : a[c] * y;  // L[c][c] = sqrt(d), L[r][c] = a / sqrt(d)
     a[c] = l;
-    if (lane == c) sInv[o + c] = y;
     if (c + 1 < 16) {
-      sCol[c & 1][r] = l;
-      // next row's entry first: column c-1 (LDS, written a step ago) and column c (readlane)
-      if (c > 0) a[c + 1] -= lprev * sCol[(c - 1) & 1][c + 1];
-      a[c + 1] -= l * readlane_f64g(l, c + 1);
+      if (c > 0) a[c + 1] -= lprev * v[c + 1];
+      if (r == c + 1) a[c + 1] -= l * l;
       d = readlane_f64g(a[c + 1], c + 1);
-      // then the rest of column c-1, off the pivot chain
+      sCol[c & 1][r] = l;
       if (c > 0) {
 #pragma clang loop unroll(full)
-        for (int cc = c + 2; cc < 16; cc++) a[cc] -= lprev * sCol[(c - 1) & 1][cc];
+        for (int cc = c + 2; cc < 16; cc++) a[cc] -= lprev * v[cc];
       }
       lprev = l;
-      __builtin_amdgcn_wave_barrier();
     }
+    if (lane == c) sInv[o + c] = y;
+    __builtin_amdgcn_wave_barrier();
   }
   if (lane < 16) {
 #pragma unroll
@@ -80,19 +87,28 @@ __device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double (*sCol)[16
 }
 
 // inverse of the 16x16 lower-triangular block at sD[o..][o..] into sLi[o..][o..]: lane c < 16
-// computes column c by forward substitution (column in registers, L from LDS).
+// computes column c of the inverse, column-oriented: x_r = v_r / L[r][r], then
+// v_r' -= L[r'][r] x_r for the rows below -- independent updates, so the dependent chain per row
+// is one multiply and one fma; the L column of the next row is read from LDS one row ahead.
 __device__ __forceinline__ void invert16(double (*sD)[GB + 1], double (*sLi)[GB + 1], const double *sInv,
                                          int o, int lane) {
   if (lane >= 16) return;
   const int c = lane;
-  d16 x;
+  d16 v, x, lc, ln;
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+  for (int rp = 1; rp < 16; rp++) lc[rp] = sD[o + rp][o];
 #pragma clang loop unroll(full)
   for (int r = 0; r < 16; r++) {
-    double v = (r == c) ? 1.0 : 0.0;
+    if (r + 1 < 16) {
 #pragma clang loop unroll(full)
-    for (int k = 0; k < r; k++) v -= sD[o + r][o + k] * x[k];
-    x[r] = (r < c) ? 0.0 : v * sInv[o + r];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int rp = r + 2; rp < 16; rp++) ln[rp] = sD[o + rp][o + r + 1];
+    }
+    x[r] = v[r] * sInv[o + r];  // zero for r < c: v stays zero above the diagonal
+#pragma clang loop unroll(full)
+    for (int rp = r + 1; rp < 16; rp++) v[rp] -= lc[rp] * x[r];
+    lc = ln;
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) sLi[o + r][o + c] = x[r];
@@ -102,29 +118,41 @@ __device__ __forceinline__ void invert16(double (*sD)[GB + 1], double (*sLi)[GB 
 // >= 192 threads of one workgroup: factor D11; [L21 = D21 L11^-T  ||  inv(L11)];
 // D22 -= L21 L21^T; factor D22; inv(L22); Li21 = -inv(L22) L21 inv(L11).  Uniform control flow.
 __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB + 1],
-                                         double (*sCol)[16], double *sInv, int *sFail, int tid) {
+                                         double (*sCol)[16], double *sInv, int *sFail, int tid,
+                                         long long *tim = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
+  int ts = 1;
+#define FSTAMP() do { if (tim && tid == 0) tim[ts++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+  FSTAMP();
   if (wave == 0) {
     if (factor16(sD, sCol, sInv, 0, lane)) *sFail = 1;
   }
   __syncthreads();
-  if (wave == 1 && lane < 16) {  // row 16 + lane of L21 by forward substitution
+  FSTAMP();
+  if (wave == 1 && lane < 16) {  // row 16 + lane of L21: x L11^T = d21, column-oriented
     const int r = 16 + lane;
-    d16 x;
+    d16 x, lc, ln;
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = sD[r][c];
+#pragma unroll
+    for (int cp = 1; cp < 16; cp++) lc[cp] = sD[cp][0];
 #pragma clang loop unroll(full)
     for (int c = 0; c < 16; c++) {
-      double v = x[c];
+      if (c + 1 < 16) {
 #pragma clang loop unroll(full)
-      for (int k = 0; k < c; k++) v -= x[k] * sD[c][k];
-      x[c] = v * sInv[c];
+        for (int cp = c + 2; cp < 16; cp++) ln[cp] = sD[cp][c + 1];
+      }
+      x[c] = x[c] * sInv[c];
+#pragma clang loop unroll(full)
+      for (int cp = c + 1; cp < 16; cp++) x[cp] -= lc[cp] * x[c];
+      lc = ln;
     }
 #pragma unroll
     for (int c = 0; c < 16; c++) sD[r][c] = x[c];
   }
   if (wave == 2) invert16(sD, sLi, sInv, 0, lane);
   __syncthreads();
+  FSTAMP();
   for (int t = tid; t < 256; t += blockDim.x) {  // D22 -= L21 L21^T (lower part)
     const int r = t >> 4, c = t & 15;
     if (c <= r) {
@@ -135,10 +163,12 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB 
     }
   }
   __syncthreads();
+  FSTAMP();
   if (wave == 0) {
     if (factor16(sD, sCol, sInv, 16, lane)) *sFail = 1;
   }
   __syncthreads();
+  FSTAMP();
   if (wave == 0) invert16(sD, sLi, sInv, 16, lane);
   // T = L21 inv(L11) into the (unused) upper-right quadrant of sLi
   for (int t = tid; t < 256; t += blockDim.x) {
@@ -149,6 +179,7 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB 
     sLi[r][16 + c] = v;
   }
   __syncthreads();
+  FSTAMP();
   double li21[(256 + 191) / 192];
   int q = 0;
   for (int t = tid; t < 256; t += blockDim.x, q++) {
@@ -159,6 +190,7 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB 
     li21[q] = v;
   }
   __syncthreads();
+  FSTAMP();
   q = 0;
   for (int t = tid; t < 256; t += blockDim.x, q++) {
     const int r = t >> 4, c = t & 15;
@@ -166,19 +198,22 @@ __device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB 
     sLi[r][16 + c] = 0.0;
   }
   __syncthreads();
+  FSTAMP();
 }
 
 // diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
 // alone only for the first panel.
-__global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status) {
+__global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status,
+                                                    long long *tim) {
   __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
   __shared__ double sCol[2][16], sInv[GB];
   __shared__ int sFail;
   const int tid = threadIdx.x;
   if (tid == 0) sFail = 0;
+  if (tim && tid == 0) tim[0] = (long long)__builtin_amdgcn_s_memtime();
   for (int t = tid; t < GB * GB; t += 256) sD[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
   __syncthreads();
-  factor32(sD, sLi, sCol, sInv, &sFail, tid);
+  factor32(sD, sLi, sCol, sInv, &sFail, tid, tim);
   double *li = linv + (size_t)(j / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
@@ -186,6 +221,7 @@ __global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, d
     li[t] = (c <= r) ? sLi[r][c] : 0.0;
   }
   if (tid == 0 && sFail) status[1] = status[3];  // status[3] = this try's stamp
+  if (tim && tid == 0) tim[15] = (long long)__builtin_amdgcn_s_memtime();
 }
 
 // trsm: X = C L_dd^-T for the 16-row tiles below the panel's diagonal block (incl. the e_a tile),
@@ -372,7 +408,7 @@ __global__ __launch_bounds__(512) void k_cholg_backward(double *Lw, int ld, int 
 static void enqueue_chain(psba_ctx *h, hipStream_t s) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
   double *Lw = h->red, *linv = h->chol_ws;
-  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, ld, 0, linv, h->status);
+  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, ld, 0, linv, h->status, h->chol_tim);
   for (int j = 0; j < n32; j += GB) {
     const int tilesBelow = nT - (j + GB) / 16;  // 16-row tiles below the panel incl. the e_a tile
     hipLaunchKernelGGL(k_cholg_trsm, dim3((tilesBelow + 3) / 4), dim3(256), 0, s, Lw, ld, j, nT, linv);

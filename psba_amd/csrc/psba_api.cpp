@@ -260,7 +260,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
-  if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 8));
+  if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
   // ---- K2 decomposition: S's lower block triangle is split into camera-row groups whose
   // packed size fits the LDS budget; every (group, point chunk) pair is one workgroup ----
   {
@@ -492,11 +492,12 @@ int psba_schur_solve(psba_handle h) {
   NEED(h, h->assembled, "psba_schur_assemble first");
   TRY(launch_chol_solve(h));
   if (h->chol_tim) {
-    long long t[8];
+    long long t[16];
     PSBA_HIP(h, hipMemcpyAsync(t, h->chol_tim, sizeof t, hipMemcpyDeviceToHost, h->stream));
     PSBA_HIP(h, hipStreamSynchronize(h->stream));
-    fprintf(stderr, "chol cycles: update %lld (staging %lld, tile loads %lld, mfma loop %lld) diag %lld (factor %lld) trsm %lld backward %lld\n",
-            t[0], t[5], t[6], t[7], t[1], t[4], t[2], t[3]);
+    fprintf(stderr, "chol diag-kernel stamps (cycles since entry):");
+    for (int k = 1; k < 16; k++) fprintf(stderr, " %lld", t[k] - t[0]);
+    fprintf(stderr, "\n");
   }
   h->assembled = false;  // S is overwritten by its factor
   h->solved = true;
