@@ -22,6 +22,7 @@ struct BackArgs {
   double *newcams, *newpts;
   double *scal;        // SC_DP_L2, SC_GAIN_DEN, SC_NEW_COST, SC_NEWP_L2 accumulate here
   double *dbg_eb;
+  const int *status;   // [0] singular-V stamp, [1] not-SPD stamp, [3] this try's stamp
   double mu;
   int nC, nA, nTiles;
   int cam_terms;       // 1 on the rank that owns the camera terms of the scalar sums
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
   // camera part (once): proposal cams + dpa and the camera terms of the scalar sums.
   // g_a here is this rank's partial; the sum over ranks of dpa.g_a is the full term.
   if (blockIdx.x == 0) {
+    // the try's status as summable flags next to the four sums (slots SC_DP_L2+4, +5), so that
+    // one all-reduce (sum) over ranks covers scalars and status
+    if (tid == 0) {
+      p.scal[SC_DP_L2 + 4] = (p.status[0] == p.status[3]) ? 1.0 : 0.0;
+      p.scal[SC_DP_L2 + 5] = (p.status[1] == p.status[3]) ? 1.0 : 0.0;
+    }
     for (int t = tid; t < p.nA; t += TILE_OBS) {
       const double d = p.dp[t], c = p.cams[t] + d;
       p.newcams[t] = c;
@@ -169,6 +176,7 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   a.newpts = h->pts[1 - h->cur];
   a.scal = h->scal;
   a.dbg_eb = h->dbg_eb;
+  a.status = h->status;
   a.mu = mu;
   a.nC = d.nC;
   a.nA = d.nA;

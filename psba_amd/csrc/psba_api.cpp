@@ -508,13 +508,13 @@ int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
   CHECK_H(h);
   NEED(h, h->solved, "psba_schur_solve first");
   TRY(launch_backsub(h, mu, false));
-  if (h->comm) {
-    RCCL(h, ncclAllReduce(h->scal + SC_DP_L2, h->scal + SC_DP_L2, 4, ncclDouble, ncclSum, h->comm,
+  if (h->comm)  // four sums + two status flags in one collective
+    RCCL(h, ncclAllReduce(h->scal + SC_DP_L2, h->scal + SC_DP_L2, 6, ncclDouble, ncclSum, h->comm,
                           h->stream));
-    RCCL(h, ncclAllReduce(h->status, h->status, 2, ncclInt, ncclMax, h->comm, h->stream));
-  }
   TRY(fetch_scalars(h));
-  const int st0 = h->h_status[0], st1 = h->h_status[1];
+  // K3 publishes the status as flags (summed over ranks): > 0 <=> flagged on some rank
+  const int st0 = h->h_scal[SC_DP_L2 + 4] > 0.0 ? h->try_id : 0;
+  const int st1 = h->h_scal[SC_DP_L2 + 5] > 0.0 ? h->try_id : 0;
   h->backsubbed = true;
   h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   if (out) {

@@ -25,7 +25,9 @@ enum {
   SC_GAIN_DEN = 2,
   SC_NEW_COST = 3,
   SC_NEWP_L2 = 4,
-  SC_MAXDIAG = 5,
+  SC_STATUS_V = 5,   // K3: 1.0 when some V_i was singular in this try (summable over ranks)
+  SC_STATUS_SPD = 6, // K3: 1.0 when the Cholesky of this try failed
+  SC_MAXDIAG = 7,
 };
 
 struct Dims {
