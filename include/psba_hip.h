@@ -224,6 +224,20 @@ int psba_profile_get(psba_handle h, int kernel, double *total_ms, int *launches)
  * (SURVEY.md section 8(d) formulas; stated in DESIGN.md) */
 int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
 
+/* ---- test hook: the static schedule of the S-assembly kernel, built on the host only ----
+ * (no device needed).  The reference decides the same placement per launch through its
+ * blkIdx_buffer look-ups (CL_files/compute_S.cl:13-22); here it is data that can be checked.
+ * info[0..5] = groups, workgroups, item slots, products, slab doubles, blocks nC(nC+1)/2.
+ * psba_schur_plan_copy: items[info[2]]; wg[info[1]][7] = group, blocks in partition, obs0, pt0,
+ * first item, end item, slab offset; blockpos[info[5]]; glo[groups+1].  Any pointer may be NULL. */
+typedef struct psba_schur_plan *psba_schur_plan_t;
+psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
+                                         const int *jidx);
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]);
+int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long long *wg,
+                         int *blockpos, int *glo);
+void psba_schur_plan_destroy(psba_schur_plan_t p);
+
 #ifdef __cplusplus
 }
 #endif

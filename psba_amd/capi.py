@@ -99,6 +99,10 @@ SIGNATURES = [
     ("psba_profile_reset", C.c_int, [_h]),
     ("psba_profile_get", C.c_int, [_h, C.c_int, _dp, _ip]),
     ("psba_algorithmic_bytes", C.c_int, [_h, C.c_int, _dp]),
+    ("psba_schur_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
+    ("psba_schur_plan_destroy", None, [C.c_void_p]),
 ]
 for _name, _res, _args in SIGNATURES:
     _f = getattr(lib, _name)
@@ -152,6 +156,30 @@ def partition_points(n_pts, iidx, nranks):
     if rc != 0:
         raise PsbaError(rc, "psba_partition_points failed")
     return out
+
+
+def schur_plan(n_cams, n_pts, iidx, jidx):
+    """The static schedule of the S-assembly kernel for a sparsity pattern (host only, no
+    device): dict with groups, items (uint64), wg [nWg,7], blockpos, glo and the counters."""
+    iidx = _c(iidx, np.int32)
+    jidx = _c(jidx, np.int32)
+    p = lib.psba_schur_plan_create(int(n_cams), int(n_pts), int(iidx.size), _i(iidx), _i(jidx))
+    if not p:
+        raise PsbaError(-1, "psba_schur_plan_create failed")
+    try:
+        info = (C.c_longlong * 6)()
+        lib.psba_schur_plan_info(p, info)
+        groups, nwg, nslots, products, slab, nblocks = (int(x) for x in info)
+        items = np.zeros(nslots, dtype=np.uint64)
+        wg = np.zeros((nwg, 7), dtype=np.int64)
+        blockpos = np.zeros(nblocks, dtype=np.int32)
+        glo = np.zeros(groups + 1, dtype=np.int32)
+        lib.psba_schur_plan_copy(p, items.ctypes.data_as(C.POINTER(C.c_ulonglong)),
+                                 wg.ctypes.data_as(C.POINTER(C.c_longlong)), _i(blockpos), _i(glo))
+    finally:
+        lib.psba_schur_plan_destroy(p)
+    return dict(groups=groups, items=items, wg=wg, blockpos=blockpos, glo=glo, products=products,
+                slab_doubles=slab)
 
 
 def shard_problem(prob, nranks, rank):

@@ -115,71 +115,87 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
     if (sEa[t] != 0.0) atomicAdd(&p.ea[t], sEa[t]);
 }
 
-// v3: the lower block triangle of S is split into camera-row groups whose packed size fits in
-// LDS; workgroup (g, chunk) walks the observations of its point chunk whose camera lies in
-// group g (a host-built compacted list, so every lane has work), one observation a per
-// thread: V*^-1 and Y_a in registers, then for every observation b <= a of the same point
-// the 6x6 product Y_a W_b^T is added into the LDS partition with ds_add_f64.  Blocks are
-// laid out with a stride of 37 doubles so that the 64 lanes of one atomic instruction (same
-// entry of 64 different blocks) fall into different banks (a stride of 36 is a 4-way
-// conflict: measured 32 vs 8 cycles per wave-instruction).  The partition is written once,
-// as plain stores, into the chunk's slab; k_schur_reduce sums the slabs in chunk order.
-// The G workgroups of one chunk are mapped to the same XCD (blockIdx % 8) so that the
-// re-reads of the chunk's W blocks are L2 hits.
+// v4: the lower block triangle of S is split into camera-row groups whose 6x6 accumulators fit
+// in LDS, and a static schedule built at upload time (schur_plan.cpp) gives every workgroup an
+// equally long list of self-contained 64-bit work items, one per product Y_a W_b^T (b <= a,
+// same point), point-major so that neighbouring lanes read the same W rows:
+//   bits 0..17 a - obs0   18..33 i - pt0   34..44 a - b   45..54 block position in the partition
+// One item per thread: all loads of the product are issued at once, V*^-1 and Y_a are formed
+// in registers and the 6x6 product is added into the LDS partition with ds_add_f64.
+//  * blocks sit at a stride of 37 doubles and the schedule deals items into rows of 16 lanes
+//    whose block positions differ mod 16, so the 16 lanes that go through the LDS together hit
+//    16 different bank pairs (measured 8 ticks per wave-instruction against 25 unscheduled);
+//  * the self-product of an observation (a == b) is symmetric, so six of its upper-triangle
+//    slots carry the e_a term  -Y_a g_b,i  instead: no separate e_a accumulators or atomics;
+//  * the partition is written once, as plain stores, into the workgroup's slab;
+//    k_schur_reduce sums the slabs of a group in a fixed order;
+//  * workgroups that work on the same stretch of points (for different camera-row groups)
+//    are mapped to the same XCD (blockIdx % 8) so that the re-reads of W are L2 hits.
 constexpr int SCHUR_THREADS = 1024;
 constexpr int BLK_STRIDE = 37;
+// slots (6 r + c, c > r) of a diagonal block that carry e_a[0..5]
+__device__ __constant__ const int EA_SLOT[6] = {1, 2, 3, 4, 5, 8};
 
 struct SchurLdsArgs {
   const double *W, *PV;
-  const int *iidx, *jidx, *ptr, *gobs, *gstart, *chunk_obs0;
+  const SchurWg *wg;
+  const unsigned long long *items;
   double *slab;
   int *status;
   double *dbg_Y, *dbg_Vinv;
   double mu;
-  int nC, nA, nGroups, nChunks, try_id;
-  unsigned long long slabStride;  // packedN + nA
-  unsigned long long packedN;
-  int glo[MAX_GROUPS + 1];
+  int nWg, try_id;
 };
 
 __device__ __forceinline__ int tri(int j) { return j * (j + 1) / 2; }
 
 // MODE is development instrumentation (ablation timing, PSBA_SCHUR_MODE): 0 = full kernel;
-// 1 = products without the LDS atomics; 2 = no product loop; 4 = zero + flush only.
+// 1 = products without the LDS atomics; 2 = no product loop; 3 = no W_b loads (wrong
+// results); 4 = zero + flush only.
 template <bool DUMP, int MODE>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
-  extern __shared__ double sPart[];  // [nblk][37] rows [lo,hi) of the block triangle, then e_a rows
+  extern __shared__ double sPart[];  // [nblk][37]
   const int tid = threadIdx.x;
-  int g, chunk;
-  if ((p.nChunks & 7) == 0) {
-    chunk = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * p.nGroups));
-    g = (blockIdx.x >> 3) % p.nGroups;
-  } else {
-    g = blockIdx.x % p.nGroups;
-    chunk = blockIdx.x / p.nGroups;
-  }
-  const int lo = p.glo[g], hi = p.glo[g + 1];
-  const int Tlo = tri(lo);
-  const int nblk = tri(hi) - Tlo;
-  double *sEa = sPart + BLK_STRIDE * nblk;
-  const int nEa = 6 * (hi - lo);
-  for (int t = tid; t < BLK_STRIDE * nblk + nEa; t += SCHUR_THREADS) sPart[t] = 0.0;
+  int w = blockIdx.x;
+  if ((p.nWg & 7) == 0) w = (blockIdx.x & 7) * (p.nWg >> 3) + (blockIdx.x >> 3);
+  const SchurWg wg = p.wg[w];
+  for (int t = tid; t < BLK_STRIDE * wg.nblk; t += SCHUR_THREADS) sPart[t] = 0.0;
   __syncthreads();
 
-  const int s0 = p.gstart[chunk * p.nGroups + g];
-  const int s1 = (MODE == 4) ? s0 : p.gstart[chunk * p.nGroups + g + 1];
+  const long long s1 = (MODE == 4) ? wg.item0 : wg.item1;
   double keep = 0.0;
-  const int obs0 = p.chunk_obs0[chunk];
-  for (int t = s0 + tid; t < s1; t += SCHUR_THREADS) {
-    const unsigned item = (unsigned)p.gobs[t];
-    const int a = obs0 + (int)(item >> 12);
-    const int kfirst = (int)((item >> 4) & 255u), kcount = (int)(item & 15u);
-    const int i = p.iidx[a], ja = p.jidx[a];
+  for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
+    const unsigned long long item = p.items[t];
+    if (item == SCHUR_NULL_ITEM) continue;
+    const int a = wg.obs0 + (int)(item & 0x3FFFFu);
+    const int i = wg.pt0 + (int)((item >> 18) & 0xFFFFu);
+    const int boff = (int)((item >> 34) & 0x7FFu);
+    const int pos = (int)((item >> 45) & 0x3FFu);
+    // every address is known now: issue all loads of the product together
     const double *pv = p.PV + 9 * (size_t)i;
-    double v[6], vi[6];
+    const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
+    const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
+    double v[6], vi[6], w[18], wb[18];
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = pv[k];
     const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const double2 q = wa[k];
+      w[2 * k] = q.x;
+      w[2 * k + 1] = q.y;
+    }
+    if (MODE == 3) {  // products without the W_b loads
+#pragma unroll
+      for (int k = 0; k < 18; k++) wb[k] = w[k] + 1.0;
+    } else if (MODE != 2) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double2 q = wb2[k];
+        wb[2 * k] = q.x;
+        wb[2 * k + 1] = q.y;
+      }
+    }
     v[0] += p.mu;
     v[3] += p.mu;
     v[5] += p.mu;
@@ -190,67 +206,46 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
       o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
     }
-    double Y[18];
-    {
-      const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
-      double w[18];
+    const bool self = boff == 0;
+    double Y[18], e[6];
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const double2 q = wa[k];
-        w[2 * k] = q.x;
-        w[2 * k + 1] = q.y;
-      }
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
-        Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
-        Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
-        Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
-        if (kfirst == 0)  // the first run of an observation also carries its e_a term
-          atomicAdd(&sEa[6 * (ja - lo) + r],
-                    -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
-      }
+    for (int r = 0; r < 6; r++) {
+      const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+      Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+      Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+      Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+      e[r] = -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2);
     }
-    if (DUMP && kfirst == 0) {
+    if (DUMP && self) {
 #pragma unroll
       for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
     }
     if (MODE == 2) {
-      keep += Y[0] + Y[17];
+      keep += Y[0] + Y[17] + e[0] + e[5];
       continue;
     }
-    double *rowbase = sPart + BLK_STRIDE * (tri(ja) - Tlo);
-    const int bfirst = p.ptr[i] + kfirst;
-    for (int b = bfirst; b < bfirst + kcount; b++) {
-      double *blk = rowbase + BLK_STRIDE * p.jidx[b];
-      const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)b);
-      double wb[18];
+    double *blk = sPart + BLK_STRIDE * pos;
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const double2 q = wb2[k];
-        wb[2 * k] = q.x;
-        wb[2 * k + 1] = q.y;
-      }
+    for (int r = 0; r < 6; r++) {
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-          const double val = -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2);
-          if (MODE == 1)
-            keep += val;
-          else
-            atomicAdd(&blk[6 * r + c], val);
-        }
+        double val = -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2);
+        // the self-product's e_a terms ride in redundant upper-triangle slots (EA_SLOT)
+        if (r == 0 && c >= 1) val = self ? e[c - 1] : val;
+        if (r == 1 && c == 2) val = self ? e[5] : val;
+        if (MODE == 1)
+          keep += val;
+        else
+          atomicAdd(&blk[6 * r + c], val);
       }
     }
   }
   if (MODE != 0 && keep == 12345.678) sPart[0] = keep;
   __syncthreads();
-  double *slab = p.slab + (size_t)chunk * p.slabStride;
-  for (int t = tid; t < 36 * nblk; t += SCHUR_THREADS)
-    slab[36 * (size_t)Tlo + t] = sPart[BLK_STRIDE * (t / 36) + t % 36];
-  for (int t = tid; t < nEa; t += SCHUR_THREADS) slab[p.packedN + 6 * lo + t] = sEa[t];
+  double *slab = p.slab + wg.slab_off;
+  for (int t = tid; t < 36 * wg.nblk; t += SCHUR_THREADS)
+    slab[t] = sPart[BLK_STRIDE * (t / 36) + t % 36];
 }
 
 // writes the padding of the reduce buffer: identity (pad_one = 1 on rank 0, else 0, so that
@@ -276,63 +271,70 @@ __device__ __forceinline__ void write_padding(double *S, int nA, int n32, double
   }
 }
 
-// sums the chunk slabs (fixed order: four interleaved chunk sequences, then their sum), adds
-// blockdiag(U) + mu_add I and g_a, and writes the padded row-major S (both block triangles)
-// and the e_a row.  64 outputs x 4 chunk sequences per workgroup.
-__global__ __launch_bounds__(256) void k_schur_reduce(const double *slab, int nChunks,
-                                                      unsigned long long slabStride,
-                                                      unsigned long long packedN, const double *U,
-                                                      const double *ga, double mu_add, int nA,
-                                                      int n32, double pad_one, double *S,
-                                                      double *ea, double *scal, int *status,
-                                                      int try_id) {
+struct SchurReduceArgs {
+  const double *slab, *U, *ga;
+  const int *posblock;  // per group, per position: (j << 16) | k of the block there, -1 = padding
+  double *S, *ea, *scal;
+  int *status;
+  double mu_add, pad_one;
+  int nA, n32, nGroups, try_id;
+  int gnwg[MAX_GROUPS], gnblk[MAX_GROUPS], gpos0[MAX_GROUPS + 1];  // gpos0: first position of a group
+  unsigned long long gslab[MAX_GROUPS];
+};
+
+// sums the slabs of each camera-row group (fixed order: four interleaved slab sequences, then
+// their sum), adds blockdiag(U) + mu_add I and g_a, and writes the padded row-major S (both
+// block triangles) and the e_a row.  Workgroups walk the slabs in storage order (64
+// consecutive doubles x 4 slab sequences each; a group's partition is a multiple of 576
+// doubles, so a workgroup never straddles groups) and scatter the few results.
+__global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   __shared__ double sAcc[4][64];
   // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
   // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
-  if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x == 4) status[3] = try_id;
-  write_padding(S, nA, n32, pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+  if (blockIdx.x == 0 && threadIdx.x < 4) p.scal[SC_DP_L2 + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 4) p.status[3] = p.try_id;
+  write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                 (size_t)gridDim.x * blockDim.x);
-  const unsigned long long total = packedN + nA;
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const unsigned long long e = (unsigned long long)blockIdx.x * 64 + o;
+  const int e = blockIdx.x * 64 + o;  // slot 36 * (global position) + rc
+  int g = 0;
+  while (g + 1 < p.nGroups && blockIdx.x * 64 >= 36 * p.gpos0[g + 1]) g++;
+  const int n = p.gnwg[g];
+  const size_t stride = (size_t)36 * p.gnblk[g];
+  const double *s = p.slab + p.gslab[g] + (e - 36 * p.gpos0[g]);
   double acc = 0.0;
-  if (e < total) {
-    int c = q;
-    for (; c + 12 < nChunks; c += 16) {
-      const double x0 = slab[(size_t)c * slabStride + e];
-      const double x1 = slab[(size_t)(c + 4) * slabStride + e];
-      const double x2 = slab[(size_t)(c + 8) * slabStride + e];
-      const double x3 = slab[(size_t)(c + 12) * slabStride + e];
-      acc += x0;
-      acc += x1;
-      acc += x2;
-      acc += x3;
-    }
-    for (; c < nChunks; c += 4) acc += slab[(size_t)c * slabStride + e];
+  int k = q;
+  for (; k + 12 < n; k += 16) {
+    const double x0 = s[(size_t)k * stride];
+    const double x1 = s[(size_t)(k + 4) * stride];
+    const double x2 = s[(size_t)(k + 8) * stride];
+    const double x3 = s[(size_t)(k + 12) * stride];
+    acc += x0;
+    acc += x1;
+    acc += x2;
+    acc += x3;
   }
+  for (; k < n; k += 4) acc += s[(size_t)k * stride];
   sAcc[q][o] = acc;
   __syncthreads();
-  if (q != 0 || e >= total) return;
+  if (q != 0) return;
   acc = ((sAcc[0][o] + sAcc[1][o]) + sAcc[2][o]) + sAcc[3][o];
-  if (e >= packedN) {
-    const int t = (int)(e - packedN);
-    ea[t] = ga[t] + acc;
-    return;
-  }
-  const int blk = (int)(e / 36), rc = (int)(e % 36);
-  int j = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
-  while (tri(j + 1) <= blk) j++;
-  while (tri(j) > blk) j--;
-  const int jb = blk - tri(j);
-  const int r = rc / 6, c = rc % 6;
+  const int jk = p.posblock[e / 36];
+  if (jk < 0) return;
+  const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
   if (j == jb) {
-    acc += U[36 * j + rc];
-    if (r == c) acc += mu_add;
-  } else {
-    S[(size_t)(6 * jb + c) * n32 + 6 * j + r] = acc;
+    // a diagonal block holds its lower triangle; six upper slots carry e_a, the rest is unused
+    if (c > r) {
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        if (rc == EA_SLOT[t]) p.ea[6 * j + t] = p.ga[6 * j + t] + acc;
+      return;
+    }
+    acc += p.U[36 * j + rc];
+    if (r == c) acc += p.mu_add;
   }
-  S[(size_t)(6 * j + r) * n32 + 6 * jb + c] = acc;
+  p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = acc;
+  p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = acc;
 }
 
 // (v1 path) S += blockdiag(U) + mu_add I on the lower block triangle, mirror to the upper
@@ -368,58 +370,63 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   SchurLdsArgs a;
   a.W = h->W;
   a.PV = h->PV;
-  a.iidx = h->iidx;
-  a.jidx = h->jidx;
-  a.ptr = h->ptr;
-  a.gobs = h->gobs;
-  a.gstart = h->gstart;
-  a.chunk_obs0 = h->chunk_obs0;
+  a.wg = h->wg;
+  a.items = h->items;
   a.slab = h->slab;
   a.status = h->status;
   a.dbg_Y = h->dbg_Y;
   a.dbg_Vinv = h->dbg_Vinv;
   a.mu = mu;
-  a.nC = d.nC;
-  a.nA = d.nA;
-  a.nGroups = h->nGroups;
-  a.nChunks = h->nChunks;
+  a.nWg = h->nWg;
   a.try_id = h->try_id;
-  a.packedN = h->packedN;
-  a.slabStride = h->packedN + d.nA;
-  size_t worst = 0;
-  for (int g = 0; g <= h->nGroups; g++) a.glo[g] = h->glo[g];
+  SchurReduceArgs r;
+  r.slab = h->slab;
+  r.U = h->U;
+  r.ga = h->ga;
+  r.posblock = h->posblock;
+  r.S = h->red;
+  r.ea = h->red + (size_t)h->n32 * h->n32;
+  r.scal = h->scal;
+  r.status = h->status;
+  r.mu_add = h->rank == 0 ? mu : 0.0;
+  r.pad_one = h->rank == 0 ? 1.0 : 0.0;
+  r.nA = d.nA;
+  r.n32 = h->n32;
+  r.nGroups = h->nGroups;
+  r.try_id = h->try_id;
+  int worst = 0;
+  r.gpos0[0] = 0;
   for (int g = 0; g < h->nGroups; g++) {
-    const size_t lo = h->glo[g], hi = h->glo[g + 1];
-    const size_t n = BLK_STRIDE * (hi * (hi + 1) / 2 - lo * (lo + 1) / 2) + 6 * (hi - lo);
-    if (n > worst) worst = n;
+    r.gnwg[g] = h->gnwg[g];
+    r.gnblk[g] = h->gnblk[g];
+    r.gslab[g] = h->gslab[g];
+    r.gpos0[g + 1] = r.gpos0[g] + h->gnblk[g];
+    if (h->gnblk[g] > worst) worst = h->gnblk[g];
   }
-  const size_t lds = sizeof(double) * worst;
-  const int grid = h->nGroups * h->nChunks;
-  const double mu_add = h->rank == 0 ? mu : 0.0;
-  const size_t total = h->packedN + d.nA;
-  const int rgrid = (int)((total + 63) / 64);
+  const size_t lds = sizeof(double) * BLK_STRIDE * (size_t)worst;
+  const int rgrid = 36 * r.gpos0[h->nGroups] / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
   {
     ProfScope ps(h, PSBA_K_SCHUR);
     const char *m = getenv("PSBA_SCHUR_MODE");
     const int mode = m ? atoi(m) : 0;
-    const dim3 G(grid), B(SCHUR_THREADS);
+    const dim3 G(h->nWg), B(SCHUR_THREADS);
     if (dump)
       hipLaunchKernelGGL((k_schur_lds<true, 0>), G, B, lds, h->stream, a);
     else if (mode == 1)
       hipLaunchKernelGGL((k_schur_lds<false, 1>), G, B, lds, h->stream, a);
     else if (mode == 2)
       hipLaunchKernelGGL((k_schur_lds<false, 2>), G, B, lds, h->stream, a);
+    else if (mode == 3)
+      hipLaunchKernelGGL((k_schur_lds<false, 3>), G, B, lds, h->stream, a);
     else if (mode == 4)
       hipLaunchKernelGGL((k_schur_lds<false, 4>), G, B, lds, h->stream, a);
     else
       hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
   }
+  PSBA_HIP(h, hipGetLastError());
   {
     ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
-    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, h->slab, h->nChunks,
-                       a.slabStride, a.packedN, h->U, h->ga, mu_add, d.nA, h->n32,
-                       h->rank == 0 ? 1.0 : 0.0, h->red, h->red + (size_t)h->n32 * h->n32, h->scal, h->status,
-                       h->try_id);
+    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, r);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
@@ -437,6 +444,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 0>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 1>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 2>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 3>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 4>, attr, dyn));
       g_lds_attr_set = true;
     }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "psba_internal.h"
@@ -102,10 +103,9 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->ga);
   dev_free(h->campart);
   dev_free(h->red);
-  dev_free(h->chunk_tile);
-  dev_free(h->gobs);
-  dev_free(h->gstart);
-  dev_free(h->chunk_obs0);
+  dev_free(h->items);
+  dev_free(h->wg);
+  dev_free(h->posblock);
   dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->chol_ws);
@@ -261,111 +261,23 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
-  // ---- K2 decomposition: S's lower block triangle is split into camera-row groups whose
-  // packed size fits the LDS budget; every (group, point chunk) pair is one workgroup ----
+  // ---- K2's static schedule (camera-row groups, workgroups, conflict-free item rows) ----
   {
-    const size_t total_blocks = (size_t)nCams * (nCams + 1) / 2;
-    h->packedN = 36 * total_blocks;
-    // LDS budget of the partition: 37 doubles per 6x6 block (padded stride), 6 per e_a row
-    size_t budget_bytes = 163840 - 1024;
-    if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_bytes = (size_t)atoi(e) * 1024;
-    const size_t budget_doubles = budget_bytes / sizeof(double);
-    h->nGroups = 0;
-    for (int G = 1; G <= MAX_GROUPS; G++) {
-      // equal-area split of the triangle into G row groups
-      std::vector<int> lo(1, 0);
-      for (int g = 1; g < G; g++) {
-        const double target = (double)total_blocks * g / G;
-        int j = lo.back();
-        while (j < nCams && (double)j * (j + 1) / 2 < target) j++;
-        if (j <= lo.back()) j = lo.back() + 1;
-        if (j > nCams) j = nCams;
-        lo.push_back(j);
-      }
-      lo.push_back(nCams);
-      size_t worst = 0;
-      bool ok = true;
-      for (int g = 0; g < G; g++) {
-        if (lo[g + 1] <= lo[g]) { ok = false; break; }
-        const size_t blk = (size_t)lo[g + 1] * (lo[g + 1] + 1) / 2 - (size_t)lo[g] * (lo[g] + 1) / 2;
-        const size_t need = 37 * blk + 6 * (size_t)(lo[g + 1] - lo[g]);
-        if (need > worst) worst = need;
-      }
-      if (ok && worst <= budget_doubles) {
-        h->nGroups = G;
-        for (int g = 0; g <= G; g++) h->glo[g] = lo[g];
-        break;
-      }
-    }
+    SchurPlanHost plan;
+    TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
     if (h->nGroups) {
-      int nChunks = 256 / h->nGroups;
-      if (nChunks < 1) nChunks = 1;
-      if (nChunks > d.nTiles) nChunks = d.nTiles;
-      if (nChunks >= 8) nChunks -= nChunks % 8;
-      h->nChunks = nChunks;
-      std::vector<int> ct((size_t)nChunks + 1);
-      for (int c = 0; c <= nChunks; c++) ct[c] = (int)((long long)d.nTiles * c / nChunks);
-      // work items: for every (chunk, group) the observations a of the chunk's points whose
-      // camera lies in the group, each split into runs of at most T partner observations
-      // b (the product loop of K2), packed as (a - chunk base) << 12 | first partner << 4 | count.
-      // Bounding the run length bounds the critical path of a workgroup (tracks have a long
-      // tail); inside a list the items are sorted by count, longest first, so that the 64
-      // lanes of a wave run the same number of iterations, and the blocks of 64 are dealt to
-      // the waves of a workgroup forwards and backwards alternately to even out their totals.
-      {
-        const int G = h->nGroups;
-        int T = 1;  // one product per work item measured fastest (67 vs 75 us at T = 4 on the venice-shaped set)
-        if (const char *e = getenv("PSBA_SCHUR_TRIPS")) T = atoi(e);
-        if (T < 1) T = 1;
-        if (T > 15) T = 15;
-        std::vector<int> grp_of_cam((size_t)nCams);
-        for (int g = 0; g < G; g++)
-          for (int j = h->glo[g]; j < h->glo[g + 1]; j++) grp_of_cam[j] = g;
-        std::vector<int> gstart((size_t)nChunks * G + 1, 0);
-        std::vector<std::vector<unsigned>> lists((size_t)nChunks * G);
-        std::vector<int> chunk_obs0((size_t)nChunks + 1);
-        for (int c = 0; c <= nChunks; c++) chunk_obs0[c] = ptr[tile_pt[ct[c]]];
-        for (int c = 0; c < nChunks; c++) {
-          const int o0 = chunk_obs0[c], o1 = chunk_obs0[c + 1];
-          if (o1 - o0 >= (1 << 20))
-            return fail(h, PSBA_E_INVALID, "point chunk with %d observations (max %d)", o1 - o0, 1 << 20);
-          for (int a = o0; a < o1; a++) {
-            auto &L = lists[(size_t)c * G + grp_of_cam[jidx[a]]];
-            const int trips = a - ptr[iidx[a]] + 1;  // partners b = ptr[i] .. a
-            for (int k = 0; k < trips; k += T) {
-              const int cnt = trips - k < T ? trips - k : T;
-              L.push_back(((unsigned)(a - o0) << 12) | ((unsigned)k << 4) | (unsigned)cnt);
-            }
-          }
-        }
-        const int WAVES = 16;
-        std::vector<unsigned> gobs;
-        std::vector<unsigned> tmp;
-        for (size_t k = 0; k < lists.size(); k++) {
-          auto &L = lists[k];
-          if (!getenv("PSBA_SCHUR_NOSORT"))
-            std::stable_sort(L.begin(), L.end(), [](unsigned x, unsigned y) { return (x & 15u) > (y & 15u); });
-          tmp = L;
-          // only rounds whose 16 blocks of 64 are all complete are permuted
-          const int fullRounds = (int)(L.size() / (size_t)(WAVES * 64));
-          for (int r = 1; r < fullRounds && T > 1 && !getenv("PSBA_SCHUR_NOSORT"); r += 2)
-            for (int w = 0; w < WAVES; w++) {
-              const size_t src = (size_t)(r * WAVES + (WAVES - 1 - w)) * 64, dst = (size_t)(r * WAVES + w) * 64;
-              std::copy(tmp.begin() + src, tmp.begin() + src + 64, L.begin() + dst);
-            }
-          gstart[k + 1] = gstart[k] + (int)L.size();
-          gobs.insert(gobs.end(), L.begin(), L.end());
-        }
-        TRY(dev_alloc(h, &h->gobs, gobs.size()));
-        TRY(dev_alloc(h, &h->gstart, gstart.size()));
-        TRY(dev_alloc(h, &h->chunk_obs0, chunk_obs0.size()));
-        PSBA_HIP(h, hipMemcpy(h->gobs, gobs.data(), sizeof(int) * gobs.size(), hipMemcpyHostToDevice));
-        PSBA_HIP(h, hipMemcpy(h->gstart, gstart.data(), sizeof(int) * gstart.size(), hipMemcpyHostToDevice));
-        PSBA_HIP(h, hipMemcpy(h->chunk_obs0, chunk_obs0.data(), sizeof(int) * chunk_obs0.size(), hipMemcpyHostToDevice));
-      }
-      TRY(dev_alloc(h, &h->chunk_tile, ct.size()));
-      TRY(dev_alloc(h, &h->slab, (size_t)nChunks * (h->packedN + d.nA)));
-      PSBA_HIP(h, hipMemcpy(h->chunk_tile, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice));
+      TRY(dev_alloc(h, &h->items, plan.items.size() ? plan.items.size() : 1));
+      TRY(dev_alloc(h, &h->wg, plan.wgs.size()));
+      TRY(dev_alloc(h, &h->posblock, plan.posblock.size()));
+      TRY(dev_alloc(h, &h->slab, plan.slab_doubles));
+      PSBA_HIP(h, hipMemcpy(h->items, plan.items.data(), sizeof(unsigned long long) * plan.items.size(), hipMemcpyHostToDevice));
+      PSBA_HIP(h, hipMemcpy(h->wg, plan.wgs.data(), sizeof(SchurWg) * plan.wgs.size(), hipMemcpyHostToDevice));
+      PSBA_HIP(h, hipMemcpy(h->posblock, plan.posblock.data(), sizeof(int) * plan.posblock.size(), hipMemcpyHostToDevice));
+      if (getenv("PSBA_SCHUR_PLAN_INFO"))
+        fprintf(stderr, "[psba] K2 plan: %d groups, %d workgroups, %lld products in %zu item slots (fill %.3f), slabs %.1f MB\n",
+                h->nGroups, h->nWg, plan.real_items, plan.items.size(),
+                plan.items.size() ? (double)plan.real_items / (double)plan.items.size() : 1.0,
+                8e-6 * (double)plan.slab_doubles);
     }
   }
   auto H2D = [&](void *dst, const void *src, size_t bytes) {
@@ -899,5 +811,62 @@ int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes) {
   if (bytes) *bytes = b;
   return PSBA_OK;
 }
+
+// ---- test hook: K2's static schedule without a device ----
+struct psba_schur_plan {
+  psba_ctx ctx;  // only the plan fields are used; no HIP call is made through it
+  psba::SchurPlanHost plan;
+  long long nBlocks = 0;
+};
+
+psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
+                                         const int *jidx) {
+  if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !iidx || !jidx) return nullptr;
+  std::vector<int> ptr((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return nullptr;
+    if (a && iidx[a] < iidx[a - 1]) return nullptr;  // point-major, as psba_upload_problem requires
+    ptr[(size_t)iidx[a] + 1]++;
+  }
+  for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[i];
+  psba_schur_plan *p = new (std::nothrow) psba_schur_plan;
+  if (!p) return nullptr;
+  p->nBlocks = (long long)nCams * (nCams + 1) / 2;
+  if (psba::build_schur_plan(&p->ctx, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), p->plan) != PSBA_OK) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]) {
+  if (!p || !info) return PSBA_E_INVALID;
+  info[0] = p->ctx.nGroups;
+  info[1] = p->ctx.nGroups ? p->ctx.nWg : 0;
+  info[2] = (long long)p->plan.items.size();
+  info[3] = p->plan.real_items;
+  info[4] = (long long)p->plan.slab_doubles;
+  info[5] = p->nBlocks;
+  return PSBA_OK;
+}
+
+int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long long *wg, int *blockpos,
+                         int *glo) {
+  if (!p) return PSBA_E_INVALID;
+  if (items) std::copy(p->plan.items.begin(), p->plan.items.end(), items);
+  if (wg)
+    for (size_t k = 0; k < p->plan.wgs.size(); k++) {
+      const psba::SchurWg &w = p->plan.wgs[k];
+      long long *o = wg + 7 * k;
+      o[0] = w.group; o[1] = w.nblk; o[2] = w.obs0; o[3] = w.pt0;
+      o[4] = w.item0; o[5] = w.item1; o[6] = (long long)w.slab_off;
+    }
+  if (blockpos) std::copy(p->plan.blockpos.begin(), p->plan.blockpos.end(), blockpos);
+  if (glo)
+    for (int g = 0; g <= p->ctx.nGroups; g++) glo[g] = p->ctx.glo[g];
+  return PSBA_OK;
+}
+
+void psba_schur_plan_destroy(psba_schur_plan_t p) { delete p; }
 
 }  // extern "C"

@@ -37,6 +37,22 @@ struct Dims {
   int maxTrack = 0;
 };
 
+// one workgroup of k_schur_lds: a range of work items of one camera-row group
+struct SchurWg {
+  int group, nblk;      // camera-row group; blocks in its LDS partition
+  int obs0, pt0;        // the items' observation / point numbers are relative to these
+  long long item0, item1;
+  unsigned long long slab_off;  // where this workgroup's partition goes in psba_ctx::slab
+};
+constexpr unsigned long long SCHUR_NULL_ITEM = ~0ull;
+struct SchurPlanHost {
+  std::vector<unsigned long long> items;
+  std::vector<SchurWg> wgs;
+  std::vector<int> blockpos;   // block (j,k) -> position in its group's partition
+  std::vector<int> posblock;   // inverse, groups concatenated: (j << 16) | k, -1 = padding
+  size_t slab_doubles = 0;
+  long long real_items = 0;
+};
 }  // namespace psba
 
 struct psba_ctx {
@@ -68,14 +84,17 @@ struct psba_ctx {
   // n32), rows nA..n32-1 identity padding, row n32 = ea, rows above zero (S_buffer, eab_buffer)
   double *red = nullptr;
   int n32 = 0;
-  // K2 (schur) decomposition: camera-row groups x point chunks, one workgroup each
-  int nGroups = 0, nChunks = 0; // nGroups == 0: fall back to global atomics
-  int glo[psba::MAX_GROUPS + 1] = {0};  // group g owns camera rows [glo[g], glo[g+1])
-  int *chunk_tile = nullptr;    // [nChunks+1] first tile of each chunk
-  int *gobs = nullptr;          // K2 work items ordered by (chunk, camera-row group): see psba_upload_problem
-  int *chunk_obs0 = nullptr;    // [nChunks+1] first observation of each chunk
-  int *gstart = nullptr;        // [nChunks*nGroups+1] offsets into gobs
-  double *slab = nullptr;       // [nChunks][packedN + nA] per-chunk partial -sum(Y W^T) | -sum(Y g_b)
+  // K2 (schur) static schedule, built once per problem by schur_plan.cpp
+  int nGroups = 0;              // camera-row groups; 0: fall back to global atomics
+  int nWg = 0;                  // workgroups of k_schur_lds
+  int glo[psba::MAX_GROUPS + 1] = {0};   // group g owns camera rows [glo[g], glo[g+1])
+  int gnwg[psba::MAX_GROUPS] = {0};      // workgroups (= slabs) of group g
+  int gnblk[psba::MAX_GROUPS] = {0};     // blocks in group g's LDS partition (padded to 16)
+  size_t gslab[psba::MAX_GROUPS] = {0};  // first double of group g's slabs
+  psba::SchurWg *wg = nullptr;  // [nWg] ordered by position in the point sequence
+  unsigned long long *items = nullptr;   // work items, one per product Y_a W_b^T (or null)
+  int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
+  double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
   hipGraphExec_t chol_graph = nullptr;  // captured panel chain of kernels_chol_graph.hip
@@ -135,6 +154,8 @@ int launch_linearize(psba_ctx *h, bool dump);
 int launch_residual(psba_ctx *h, int which, double *ex_out_dev);
 int launch_max_diag(psba_ctx *h);
 // kernels_schur.hip
+int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
+                     const int *ptr, SchurPlanHost &out);
 int launch_schur(psba_ctx *h, double mu, bool dump);
 // kernels_chol.hip
 int launch_chol_solve(psba_ctx *h);

@@ -1,0 +1,207 @@
+// schur_plan.cpp -- host-side static schedule of K2 (the S / e_a assembly kernel).
+//
+// The sparsity of a bundle-adjustment problem (which camera sees which point) is fixed for the
+// whole LM run, so everything about the scatter  S_jk -= Y_ij W_ik^T  that does not depend on
+// values is decided once, at upload time, here (the reference decides the same things per launch
+// through blkIdx_buffer look-ups in CL_files/compute_S.cl:13-22 and compute_Y.cl:14-20):
+//
+//  * S's lower block triangle is split into camera-row groups whose 6x6 accumulators fit in
+//    one workgroup's LDS;
+//  * one work item per product (a, b), b <= a in the same point; the items of a group, in
+//    point-major order, are cut into equally long ranges, one per workgroup, and the groups get
+//    workgroups in proportion to their items -- every workgroup has the same amount of work;
+//  * where a block lives inside its group's LDS partition is chosen so that the 16 bank pairs
+//    of the LDS receive equal traffic, and the items of a workgroup are then dealt into rows of
+//    16 lanes whose target blocks fall into 16 different bank pairs: a ds_add_f64
+//    wave-instruction over such rows does not serialise (measured, scripts/ubench_lds.hip:
+//    8 ticks against 25 for unordered targets).  Holes are null items.
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "psba_internal.h"
+
+namespace psba {
+
+namespace {
+inline long long tri(long long j) { return j * (j + 1) / 2; }
+constexpr int ROW = 16;       // lanes that go through the LDS together; bank pairs of a 64-bit access
+int WINDOW = 8;               // open rows while dealing: more rows fill better but spread a point's
+                              // products over more waves (measured optimum on venice-shaped: 8)
+}  // namespace
+
+int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
+                     const int *ptr, SchurPlanHost &out) {
+  (void)nPts;
+  const long long total_blocks = tri(nCams);
+  if (const char *e = getenv("PSBA_SCHUR_WINDOW")) WINDOW = atoi(e) > 0 ? atoi(e) : 1;
+  h->packedN = 36 * (size_t)total_blocks;
+  h->nGroups = 0;
+  if (nCams >= 2048) return PSBA_OK;  // boff field: track length < 2048; fall back to the atomic kernel
+  // ---- camera-row groups by LDS budget: 37 doubles per block, block count padded to 16 ----
+  // 100 KiB rather than all 160: smaller partitions mean less slab traffic (flush + reduce),
+  // which on venice-shaped outweighs the loss of locality from more groups (scripts/k2_lds_sweep.sh)
+  size_t budget_bytes = 100 * 1024;
+  if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_bytes = (size_t)atoi(e) * 1024;
+  const size_t budget_blocks = budget_bytes / sizeof(double) / 37;
+  std::vector<int> lo;
+  for (int G = 1; G <= MAX_GROUPS && !h->nGroups; G++) {
+    lo.assign(1, 0);
+    for (int g = 1; g < G; g++) {  // equal-area split of the triangle
+      const double target = (double)total_blocks * g / G;
+      int j = lo.back();
+      while (j < nCams && (double)tri(j) < target) j++;
+      if (j <= lo.back()) j = lo.back() + 1;
+      if (j > nCams) j = nCams;
+      lo.push_back(j);
+    }
+    lo.push_back(nCams);
+    bool ok = true;
+    for (int g = 0; g < G && ok; g++) {
+      const long long nb = tri(lo[g + 1]) - tri(lo[g]);
+      ok = lo[g + 1] > lo[g] && (size_t)((nb + ROW - 1) / ROW * ROW) <= budget_blocks && nb <= 1008;
+    }
+    if (ok) h->nGroups = G;
+  }
+  if (!h->nGroups) return PSBA_OK;
+  const int G = h->nGroups;
+  for (int g = 0; g <= G; g++) h->glo[g] = lo[g];
+  std::vector<int> grp_of_cam((size_t)nCams);
+  for (int g = 0; g < G; g++)
+    for (int j = lo[g]; j < lo[g + 1]; j++) grp_of_cam[j] = g;
+
+  // ---- traffic per block and per group ----
+  std::vector<long long> traffic((size_t)total_blocks, 0), gitems((size_t)G, 0);
+  for (int a = 0; a < nObs; a++) {
+    const int ja = jidx[a];
+    for (int b = ptr[iidx[a]]; b <= a; b++) traffic[(size_t)(tri(ja) + jidx[b])]++;
+    gitems[grp_of_cam[ja]] += a - ptr[iidx[a]] + 1;
+  }
+  const long long total_items = std::accumulate(gitems.begin(), gitems.end(), 0LL);
+
+  // ---- block -> position inside the group's partition: busiest blocks first, each to the
+  // bank pair (position mod 16) with the least traffic so far that still has a free position ----
+  out.blockpos.assign((size_t)total_blocks, 0);
+  for (int g = 0; g < G; g++) {
+    const long long b0 = tri(lo[g]), nb = tri(lo[g + 1]) - b0;
+    const int per = (int)((nb + ROW - 1) / ROW);
+    h->gnblk[g] = per * ROW;
+    std::vector<int> order((size_t)nb);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return traffic[(size_t)(b0 + x)] > traffic[(size_t)(b0 + y)]; });
+    long long load[ROW] = {0};
+    int used[ROW] = {0};
+    for (int k : order) {
+      int best = -1;
+      for (int r = 0; r < ROW; r++)
+        if (used[r] < per && (best < 0 || load[r] < load[best])) best = r;
+      out.blockpos[(size_t)(b0 + k)] = used[best] * ROW + best;
+      used[best]++;
+      load[best] += traffic[(size_t)(b0 + k)];
+    }
+  }
+
+  out.posblock.clear();
+  for (int g = 0; g < G; g++) {
+    const size_t base = out.posblock.size();
+    out.posblock.resize(base + (size_t)h->gnblk[g], -1);
+    for (int j = lo[g]; j < lo[g + 1]; j++)
+      for (int k = 0; k <= j; k++) out.posblock[base + (size_t)out.blockpos[(size_t)(tri(j) + k)]] = (j << 16) | k;
+  }
+
+  // ---- workgroups: about one per CU, shared between the groups in proportion to their items ----
+  int nWg = 256;
+  {
+    const long long cap = total_items / 512;  // small problems: no point in near-empty workgroups
+    if (cap < nWg) nWg = (int)(cap < G ? G : cap);
+    if (nWg >= 16) nWg -= nWg % 8;
+  }
+  std::vector<int> gnwg((size_t)G, 1);
+  {
+    int left = nWg - G;
+    std::vector<double> want((size_t)G);
+    for (int g = 0; g < G; g++) want[g] = total_items ? (double)gitems[g] * nWg / (double)total_items : 1.0;
+    while (left > 0) {  // largest remaining deficit first
+      int best = 0;
+      for (int g = 1; g < G; g++)
+        if (want[g] - gnwg[g] > want[best] - gnwg[best]) best = g;
+      gnwg[best]++;
+      left--;
+    }
+  }
+  h->nWg = nWg;
+  size_t slab_total = 0;
+  for (int g = 0; g < G; g++) {
+    h->gnwg[g] = gnwg[g];
+    h->gslab[g] = slab_total;
+    slab_total += (size_t)gnwg[g] * 36 * h->gnblk[g];
+  }
+  out.slab_doubles = slab_total;
+
+  // ---- items of each group in point-major order, cut into gnwg[g] equal ranges ----
+  struct Raw { int a, i, boff, pos; };
+  std::vector<std::vector<Raw>> raw((size_t)G);
+  for (int g = 0; g < G; g++) raw[g].reserve((size_t)gitems[g]);
+  for (int a = 0; a < nObs; a++) {
+    const int ja = jidx[a], i = iidx[a], g = grp_of_cam[ja];
+    for (int b = ptr[i]; b <= a; b++)
+      raw[g].push_back({a, i, a - b, out.blockpos[(size_t)(tri(ja) + jidx[b])]});
+  }
+  struct WgTmp { SchurWg w; double where; };
+  std::vector<WgTmp> wgs;
+  out.items.clear();
+  for (int g = 0; g < G; g++) {
+    const size_t n = raw[g].size();
+    for (int k = 0; k < gnwg[g]; k++) {
+      const size_t r0 = n * k / gnwg[g], r1 = n * (k + 1) / gnwg[g];
+      SchurWg w{};
+      w.group = g;
+      w.nblk = h->gnblk[g];
+      w.slab_off = h->gslab[g] + (size_t)k * 36 * h->gnblk[g];
+      w.obs0 = r1 > r0 ? raw[g][r0].a : 0;
+      w.pt0 = r1 > r0 ? raw[g][r0].i : 0;
+      if (r1 > r0 && (raw[g][r1 - 1].a - w.obs0 >= (1 << 18) || raw[g][r1 - 1].i - w.pt0 >= (1 << 16))) {
+        h->nGroups = 0;  // the item encoding does not hold this range: atomic kernel instead
+        return PSBA_OK;
+      }
+      // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
+      const size_t base = out.items.size();
+      size_t closed = 0;  // rows [0, closed) are final
+      std::vector<uint16_t> mask;
+      std::vector<int> fill;
+      auto row_ptr = [&](size_t r) { return out.items.data() + base + r * ROW; };
+      for (size_t t = r0; t < r1; t++) {
+        const Raw &it = raw[g][t];
+        const unsigned long long enc = (unsigned long long)(it.a - w.obs0) |
+                                       ((unsigned long long)(it.i - w.pt0) << 18) |
+                                       ((unsigned long long)it.boff << 34) |
+                                       ((unsigned long long)it.pos << 45);
+        const uint16_t bit = (uint16_t)(1u << (it.pos % ROW));
+        size_t r = closed;
+        while (r < mask.size() && (mask[r] & bit)) r++;
+        if (r == mask.size()) {
+          mask.push_back(0);
+          fill.push_back(0);
+          out.items.resize(base + mask.size() * ROW, SCHUR_NULL_ITEM);
+        }
+        row_ptr(r)[fill[r]++] = enc;
+        mask[r] |= bit;
+        while (closed < mask.size() && (fill[closed] == ROW || mask.size() - closed > (size_t)WINDOW)) closed++;
+      }
+      w.item0 = (long long)base;
+      w.item1 = (long long)out.items.size();
+      wgs.push_back({w, n ? (double)(r0 + r1) / (2.0 * (double)n) : 0.0});
+    }
+  }
+  // workgroups ordered by where in the point sequence they work: neighbours (which re-read the
+  // same W rows for different camera-row groups) land on the same XCD, see k_schur_lds
+  std::stable_sort(wgs.begin(), wgs.end(), [](const WgTmp &x, const WgTmp &y) { return x.where < y.where; });
+  out.wgs.clear();
+  for (auto &t : wgs) out.wgs.push_back(t.w);
+  out.real_items = total_items;
+  return PSBA_OK;
+}
+
+}  // namespace psba

@@ -80,3 +80,68 @@ def test_partition_more_ranks_than_points():
     import psba_amd
     b = psba_amd.partition_points(2, np.array([0, 0, 1], dtype=np.int32), 4)
     assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
+
+
+def _check_plan(nC, nP, iidx, jidx):
+    """Every product (a, b <= a, same point) appears exactly once, in the workgroup list of its
+    camera-row group, at its block's position; rows of 16 item slots hit 16 different bank
+    pairs; workgroup lists are equally long within a group."""
+    from psba_amd import capi
+    plan = capi.schur_plan(nC, nP, iidx, jidx)
+    assert plan["groups"] >= 1
+    items, wg, pos, glo = plan["items"], plan["wg"], plan["blockpos"], plan["glo"]
+    ptr = np.searchsorted(iidx, np.arange(nP + 1))
+    tri = lambda j: j * (j + 1) // 2
+    # block positions: a bijection into the padded partition of the block's group
+    for g in range(plan["groups"]):
+        b0, b1 = tri(int(glo[g])), tri(int(glo[g + 1]))
+        ps = pos[b0:b1]
+        assert len(set(ps.tolist())) == b1 - b0 and ps.min() >= 0
+        nblk = {int(w[1]) for w in wg if w[0] == g}
+        assert len(nblk) == 1 and ps.max() < nblk.pop() <= (b1 - b0 + 15) // 16 * 16
+    seen = set()
+    slabs = set()
+    for w in wg:
+        g, nblk, obs0, pt0, s0, s1, slab = (int(x) for x in w)
+        assert s0 % 16 == 0 and s1 % 16 == 0 and (g, slab) not in slabs
+        slabs.add((g, slab))
+        it = items[s0:s1]
+        live = it != np.uint64(0xFFFFFFFFFFFFFFFF)
+        a = obs0 + (it & np.uint64(0x3FFFF)).astype(np.int64)
+        i = pt0 + ((it >> np.uint64(18)) & np.uint64(0xFFFF)).astype(np.int64)
+        boff = ((it >> np.uint64(34)) & np.uint64(0x7FF)).astype(np.int64)
+        p = ((it >> np.uint64(45)) & np.uint64(0x3FF)).astype(np.int64)
+        for r in range(0, len(it), 16):
+            q = p[r:r + 16][live[r:r + 16]] % 16
+            assert len(set(q.tolist())) == len(q)
+        a, i, boff, p = a[live], i[live], boff[live], p[live]
+        b = a - boff
+        assert (iidx[a] == i).all() and (iidx[b] == i).all() and (b >= ptr[i]).all()
+        ja, jb = jidx[a].astype(np.int64), jidx[b].astype(np.int64)
+        assert ((ja >= glo[g]) & (ja < glo[g + 1])).all()
+        assert (pos[ja * (ja + 1) // 2 + jb] == p).all()
+        keys = set(zip(a.tolist(), b.tolist()))
+        assert len(keys) == len(a) and not (keys & seen)
+        seen |= keys
+    want = int(((np.arange(len(iidx)) - ptr[iidx]) + 1).sum())
+    assert len(seen) == want == plan["products"]
+    # balance: item counts of the workgroups of one group differ by at most one
+    for g in range(plan["groups"]):
+        n = [int(((items[int(w[4]):int(w[5])]) != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()) for w in wg if w[0] == g]
+        assert max(n) - min(n) <= 1
+    return plan
+
+
+def test_schur_plan_small(problems):
+    for name in ("7cams", "54cams"):
+        pr = problems[name]
+        _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+
+
+def test_schur_plan_venice_shaped():
+    from psba_amd import synth
+    pr = synth.venice_shaped()
+    plan = _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+    # the bank-pair schedule should cost little padding on a realistic problem
+    assert plan["products"] / len(plan["items"]) > 0.75
+    assert len(plan["wg"]) == 256
