@@ -7,9 +7,9 @@
 // the forward solve is free; replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
 // CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19).  The reference chains ~nA
 // device-enqueued launches of 3x3 blocks; here a panel is three steps:
-//   diag    one workgroup factors the 32x32 diagonal block (two 16-step factorizations with rows
-//           in registers + a 16x16 update) and inverts the factor -- fused into the tail of the
-//           previous update;
+//   diag    one wave factors the 32x32 diagonal block (4-column panels with rows in registers,
+//           rank-4 MFMA updates of register-resident tiles) while a second wave inverts the
+//           factor in its wake -- fused into the tail of the previous update;
 //   trsm    one wave per 16-row tile below: X = C L_dd^-T as a 16x32x32 MFMA product;
 //   update  one wave per 16x16 tile of the trailing matrix: C -= X_r X_c^T with
 //           v_mfma_f64_16x16x4_f64 (K = 32), operands fetched as 64-byte pieces per lane.
@@ -24,6 +24,8 @@ namespace psba {
 
 constexpr int GB = 32;  // panel width
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) double lds_double;
 typedef double d16 __attribute__((ext_vector_type(16)));  // SSA vector: never demoted to scratch
 
 __device__ __forceinline__ double readlane_f64g(double v, int srclane) {
@@ -32,195 +34,228 @@ __device__ __forceinline__ double readlane_f64g(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-// In-place Cholesky of the 16x16 block at sD[o..o+15][o..o+15] by one wave (lanes 0..15 hold
-// the rows in registers); sInv[o+c] = 1/L[c][c].  Returns true on a non-positive / non-finite
-// pivot.  The dependent chain per column is kept to rsq + two Newton steps + one v_readlane:
-//  * the finished column c is broadcast through LDS (sCol, double-buffered) and consumed one
-//    step later; its reads are issued at the top of the next step, ahead of the rsq chain;
-//  * the next pivot needs column c only through the next row's own entry (l * l in the diagonal
-//    lane), so no cross-lane traffic sits between two pivots except the readlane of the pivot.
-// Invariant at the top of step c: a[c] holds columns < c-1 for every lane, column c-1 only in
-// the diagonal lane (r == c), and d = the finished pivot a[c][c] is known to all lanes.
-__device__ __forceinline__ bool factor16(double (*sD)[GB + 1], double (*sCol)[16], double *sInv, int o,
-                                         int lane) {
-  const int r = lane & 15;
-  d16 a;
-#pragma unroll
-  for (int c = 0; c < 16; c++) a[c] = sD[o + r][o + c];
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+// ---- the 32x32 diagonal block: four waves of one workgroup, no workgroup barrier inside ----
+// The serial part of the whole solve is the chain of nA pivots, so everything that is not a
+// pivot step is moved off the wave that runs the chain:
+//   wave 0  pivot wave: panels of four columns with lane = row and the four columns in
+//           registers.  Per column the dependent chain is readlane(pivot) -> rsq + two Newton
+//           steps -> scale -> <= 3 (readlane, fma).  The panel's own rank-4 update of the NEXT
+//           panel's columns is applied here in the row layout (16 fma with readlane scalars);
+//   wave 2  tile wave: keeps the trailing matrix as three 16x16 tiles in the MFMA accumulator
+//           layout, applies each published panel as one v_mfma_f64_16x16x4_f64 per tile and
+//           stages the columns of panel p+2 (updates <= p applied) for the pivot wave;
+//   wave 1  inverse of the upper-left 16x16 of the factor, column c per lane, rows following
+//           the panels as they are published; then T = L21 inv(L11) by MFMA;
+//   wave 3  inverse of the lower-right 16x16 the same way, then inv21 = -inv(L22) T by MFMA.
+// Progress is published through LDS words (one writer each): sFlag[0] = panels in sD,
+// sFlag[1] = panels staged by the tile wave (+2), sFlag[2] = tile wave has loaded its tiles,
+// sFlag[3] = T is in LDS.  A wave's LDS operations complete in order, so data written before a
+// flag is visible to whoever sees the flag.  No wave exits early, so every wait ends.
+struct Factor32Lds {
+  double D[GB][GB + 1];   // in: the block (lower triangle valid); out: its factor, zeros above
+  double Li[GB][GB + 1];  // out: inverse of the factor (lower triangle valid)
+  double next[2][GB][4];  // staged panels
+  double inv[GB];         // 1 / L[r][r]
+  int flag[4];
+  int fail;
+};
+
+__device__ __forceinline__ void f32_wait(int *flag, int v) {
+  while (__hip_atomic_load((lds_int *)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void f32_post(int *flag, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store((lds_int *)flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane) {
+  const int row = lane & 31;
   bool bad = false;
-  double d = readlane_f64g(a[0], 0);
-  double lprev = 0.0;
+  d4 a, ap = {0, 0, 0, 0};
 #pragma clang loop unroll(full)
-  for (int c = 0; c < 16; c++) {
-    d16 v;  // column c-1 of L as broadcast by its owners (entries c..15 used)
-    if (c > 0) {
-#pragma clang loop unroll(full)
-      for (int cc = c; cc < 16; cc++) v[cc] = sCol[(c - 1) & 1][cc];
-    }
-    bad |= !(d > 0.0);
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * (1.5 - 0.5 * d * y * y);
-    y = y * (1.5 - 0.5 * d * y * y);
-    if (c > 0 && r != c) a[c] -= lprev * v[c];
-    const double l = (r == c) ? d * y : a[c] * y;  // L[c][c] = sqrt(d), L[r][c] = a / sqrt(d)
-    a[c] = l;
-    if (c + 1 < 16) {
-      if (c > 0) a[c + 1] -= lprev * v[c + 1];
-      if (r == c + 1) a[c + 1] -= l * l;
-      d = readlane_f64g(a[c + 1], c + 1);
-      sCol[c & 1][r] = l;
-      if (c > 0) {
-#pragma clang loop unroll(full)
-        for (int cc = c + 2; cc < 16; cc++) a[cc] -= lprev * v[cc];
-      }
-      lprev = l;
-    }
-    if (lane == c) sInv[o + c] = y;
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (lane < 16) {
+  for (int q = 0; q < 8; q++) {
+    const int j0 = 4 * q;
+    if (q < 2) {
 #pragma unroll
-    for (int c = 0; c < 16; c++) sD[o + r][o + c] = (c <= r) ? a[c] : 0.0;
-    if (!isfinite(a[r])) bad = true;
+      for (int k = 0; k < 4; k++) a[k] = s.D[row][j0 + k];
+    } else {
+      // flag and data are read in one batch (volatile: issued in this order, and a wave's LDS
+      // reads complete in order), so a ready flag costs one LDS round trip, not two
+      int f;
+      do {
+        f = *(volatile lds_int *)&s.flag[1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] = *(volatile lds_double *)&s.next[q & 1][row][k];
+      } while (f < q - 1);
+    }
+    if (q > 0) {  // rank-4 update by the previous panel, in the row layout
+#pragma clang loop unroll(full)
+      for (int k2 = 0; k2 < 4; k2++)
+#pragma clang loop unroll(full)
+        for (int k = 0; k < 4; k++) a[k2] -= ap[k] * readlane_f64g(ap[k], j0 + k2);
+    }
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; k++) {
+      const double d = readlane_f64g(a[k], j0 + k);
+      bad |= !(d > 0.0) || !(d < 1.7e308);
+      const double y = rsqrt_nr(d);
+      const double l = a[k] * y;  // the pivot row gets d / sqrt(d)
+      a[k] = l;
+#pragma clang loop unroll(full)
+      for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= l * readlane_f64g(l, j0 + k2);
+      if (lane == 0) s.inv[j0 + k] = y;
+    }
+    if (q == 0) f32_wait(&s.flag[2], 1);  // the tile wave reads the original block first
+    if (lane < 32) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) s.D[row][j0 + k] = (row >= j0 + k) ? a[k] : 0.0;
+    }
+    f32_post(&s.flag[0], q + 1, lane);
+    ap = a;
   }
   return bad;
 }
 
-// inverse of the 16x16 lower-triangular block at sD[o..][o..] into sLi[o..][o..]: lane c < 16
-// computes column c of the inverse, column-oriented: x_r = v_r / L[r][r], then
-// v_r' -= L[r'][r] x_r for the rows below -- independent updates, so the dependent chain per row
-// is one multiply and one fma; the L column of the next row is read from LDS one row ahead.
-__device__ __forceinline__ void invert16(double (*sD)[GB + 1], double (*sLi)[GB + 1], const double *sInv,
-                                         int o, int lane) {
-  if (lane >= 16) return;
-  const int c = lane;
-  d16 v, x, lc, ln;
+__device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
+  const int col = lane & 15, rc = lane >> 4;
+  d4 T00, T10, T11;
 #pragma unroll
-  for (int r = 0; r < 16; r++) v[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-  for (int rp = 1; rp < 16; rp++) lc[rp] = sD[o + rp][o];
-#pragma clang loop unroll(full)
-  for (int r = 0; r < 16; r++) {
-    if (r + 1 < 16) {
-#pragma clang loop unroll(full)
-      for (int rp = r + 2; rp < 16; rp++) ln[rp] = sD[o + rp][o + r + 1];
-    }
-    x[r] = v[r] * sInv[o + r];  // zero for r < c: v stays zero above the diagonal
-#pragma clang loop unroll(full)
-    for (int rp = r + 1; rp < 16; rp++) v[rp] -= lc[rp] * x[r];
-    lc = ln;
+  for (int r = 0; r < 4; r++) {
+    T00[r] = s.D[rc + 4 * r][col];
+    T10[r] = s.D[16 + rc + 4 * r][col];
+    T11[r] = s.D[16 + rc + 4 * r][16 + col];
   }
+  asm volatile("" ::"v"(T00), "v"(T10), "v"(T11));  // the loads are complete before the post
+  f32_post(&s.flag[2], 1, lane);
+#pragma clang loop unroll(full)
+  for (int p = 0; p < 6; p++) {  // panel p+2 <= 7 is the last one to stage
+    const int j0 = 4 * p;
+    f32_wait(&s.flag[0], p + 1);
+    const double a1 = s.D[16 + col][j0 + rc];
+    if (p < 2) {  // columns < 16 are staged for panels 2, 3 only
+      const double a0 = s.D[col][j0 + rc];
+      T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, a0, T00, 0, 0, 0);
+      T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, a0, T10, 0, 0, 0);
+    }
+    T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, a1, T11, 0, 0, 0);
+    const int j2 = j0 + 8;  // first column of panel p + 2
+    if (j2 < 16) {
+      if (col >= j2 && col < j2 + 4) {
 #pragma unroll
-  for (int r = 0; r < 16; r++) sLi[o + r][o + c] = x[r];
+        for (int r = 0; r < 4; r++) {
+          s.next[p & 1][rc + 4 * r][col - j2] = T00[r];
+          s.next[p & 1][16 + rc + 4 * r][col - j2] = T10[r];
+        }
+      }
+    } else if (col >= j2 - 16 && col < j2 - 12) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) s.next[p & 1][16 + rc + 4 * r][col - (j2 - 16)] = T11[r];
+    }
+    f32_post(&s.flag[1], p + 1, lane);
+  }
 }
 
-// Factor the 32x32 block held in sD (lower triangle valid) and invert the factor into sLi, with
-// >= 192 threads of one workgroup: factor D11; [L21 = D21 L11^-T  ||  inv(L11)];
-// D22 -= L21 L21^T; factor D22; inv(L22); Li21 = -inv(L22) L21 inv(L11).  Uniform control flow.
-__device__ __forceinline__ void factor32(double (*sD)[GB + 1], double (*sLi)[GB + 1],
-                                         double (*sCol)[16], double *sInv, int *sFail, int tid,
-                                         long long *tim = nullptr) {
+// rows [o, o+16) of the inverse of the diagonal 16x16 block at (o, o): lane c owns column o + c
+template <int O>
+__device__ __forceinline__ d16 f32_inverse16(Factor32Lds &s, int lane) {
+  const int c = lane & 15;
+  d16 x;
+#pragma clang loop unroll(full)
+  for (int p = 0; p < 4; p++) {
+    f32_wait(&s.flag[0], O / 4 + p + 1);
+#pragma clang loop unroll(full)
+    for (int k = 0; k < 4; k++) {
+      const int r = 4 * p + k;
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma clang loop unroll(full)
+      for (int m = 0; m < r; m++) v -= s.D[O + r][O + m] * x[m];
+      const double xr = v * s.inv[O + r];
+      x[r] = xr;
+      // pin the row here: otherwise the compiler sinks the arithmetic below the last wait and
+      // keeps every L value read so far in registers
+      asm volatile("" ::"v"(xr));
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) s.Li[O + r][O + c] = x[r];
+  }
+  return x;
+}
+
+// 16x16x16 product of two LDS-resident blocks in the MFMA operand layouts: A[i][k] at
+// pa[i * lda + k], B[k][j] at pb[k * ldb + j]
+__device__ __forceinline__ d4 f32_mm16(const double *pa, int lda, const double *pb, int ldb, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  d4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[li * lda + 4 * t + lk], pb[(4 * t + lk) * ldb + li], acc, 0, 0, 0);
+  return acc;
+}
+
+// Factor the 32x32 block held in s.D (lower triangle valid) and invert the factor into s.Li.
+// The caller has zeroed s.flag[] / s.fail and synchronised; needs waves 0..3 of the workgroup.
+__device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
-  int ts = 1;
-#define FSTAMP() do { if (tim && tid == 0) tim[ts++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-  FSTAMP();
+  const int col = lane & 15, rc = lane >> 4;
   if (wave == 0) {
-    if (factor16(sD, sCol, sInv, 0, lane)) *sFail = 1;
-  }
-  __syncthreads();
-  FSTAMP();
-  if (wave == 1 && lane < 16) {  // row 16 + lane of L21: x L11^T = d21, column-oriented
-    const int r = 16 + lane;
-    d16 x, lc, ln;
+    if (f32_pivot_wave(s, lane)) s.fail = 1;
+    if (tim && lane == 0) tim[3] = (long long)__builtin_amdgcn_s_memtime();
+  } else if (wave == 2) {
+    f32_tile_wave(s, lane);
+  } else if (wave == 1) {
+    f32_inverse16<0>(s, lane);
+    // T = L21 inv(L11) into the (otherwise unused) upper-right quadrant of Li
+    f32_wait(&s.flag[0], 4);
+    const d4 t = f32_mm16(&s.D[16][0], GB + 1, &s.Li[0][0], GB + 1, lane);
 #pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = sD[r][c];
+    for (int r = 0; r < 4; r++) s.Li[rc + 4 * r][16 + col] = t[r];
+    f32_post(&s.flag[3], 1, lane);
+  } else if (wave == 3) {
+    f32_inverse16<16>(s, lane);
+    f32_wait(&s.flag[3], 1);
+    const d4 t = f32_mm16(&s.Li[16][16], GB + 1, &s.Li[0][16], GB + 1, lane);
 #pragma unroll
-    for (int cp = 1; cp < 16; cp++) lc[cp] = sD[cp][0];
-#pragma clang loop unroll(full)
-    for (int c = 0; c < 16; c++) {
-      if (c + 1 < 16) {
-#pragma clang loop unroll(full)
-        for (int cp = c + 2; cp < 16; cp++) ln[cp] = sD[cp][c + 1];
-      }
-      x[c] = x[c] * sInv[c];
-#pragma clang loop unroll(full)
-      for (int cp = c + 1; cp < 16; cp++) x[cp] -= lc[cp] * x[c];
-      lc = ln;
+    for (int r = 0; r < 4; r++) {
+      s.Li[16 + rc + 4 * r][col] = -t[r];
+      s.Li[rc + 4 * r][16 + col] = 0.0;  // T is consumed: Li is read as a full 32x32 by the trsm
     }
-#pragma unroll
-    for (int c = 0; c < 16; c++) sD[r][c] = x[c];
-  }
-  if (wave == 2) invert16(sD, sLi, sInv, 0, lane);
-  __syncthreads();
-  FSTAMP();
-  for (int t = tid; t < 256; t += blockDim.x) {  // D22 -= L21 L21^T (lower part)
-    const int r = t >> 4, c = t & 15;
-    if (c <= r) {
-      double v = sD[16 + r][16 + c];
-#pragma unroll
-      for (int k = 0; k < 16; k++) v -= sD[16 + r][k] * sD[16 + c][k];
-      sD[16 + r][16 + c] = v;
-    }
+    if (tim && lane == 0) tim[4] = (long long)__builtin_amdgcn_s_memtime();
   }
   __syncthreads();
-  FSTAMP();
-  if (wave == 0) {
-    if (factor16(sD, sCol, sInv, 16, lane)) *sFail = 1;
-  }
-  __syncthreads();
-  FSTAMP();
-  if (wave == 0) invert16(sD, sLi, sInv, 16, lane);
-  // T = L21 inv(L11) into the (unused) upper-right quadrant of sLi
-  for (int t = tid; t < 256; t += blockDim.x) {
-    const int r = t >> 4, c = t & 15;
-    double v = 0.0;
-#pragma unroll
-    for (int m = 0; m < 16; m++) v += sD[16 + r][m] * sLi[m][c];  // inv(L11) is lower: zeros above
-    sLi[r][16 + c] = v;
-  }
-  __syncthreads();
-  FSTAMP();
-  double li21[(256 + 191) / 192];
-  int q = 0;
-  for (int t = tid; t < 256; t += blockDim.x, q++) {
-    const int r = t >> 4, c = t & 15;
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) v -= sLi[16 + r][16 + k] * sLi[k][16 + c];
-    li21[q] = v;
-  }
-  __syncthreads();
-  FSTAMP();
-  q = 0;
-  for (int t = tid; t < 256; t += blockDim.x, q++) {
-    const int r = t >> 4, c = t & 15;
-    sLi[16 + r][c] = li21[q];
-    sLi[r][16 + c] = 0.0;
-  }
-  __syncthreads();
-  FSTAMP();
 }
 
 // diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
 // alone only for the first panel.
 __global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status,
                                                     long long *tim) {
-  __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
-  __shared__ double sCol[2][16], sInv[GB];
-  __shared__ int sFail;
+  __shared__ Factor32Lds s;
   const int tid = threadIdx.x;
-  if (tid == 0) sFail = 0;
+  if (tid < 4) s.flag[tid] = 0;
+  if (tid == 4) s.fail = 0;
   if (tim && tid == 0) tim[0] = (long long)__builtin_amdgcn_s_memtime();
-  for (int t = tid; t < GB * GB; t += 256) sD[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
+  for (int t = tid; t < GB * GB; t += 256) s.D[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
   __syncthreads();
-  factor32(sD, sLi, sCol, sInv, &sFail, tid, tim);
+  if (tim && tid == 0) tim[1] = (long long)__builtin_amdgcn_s_memtime();
+  factor32(s, tid, tim);
+  if (tim && tid == 0) tim[2] = (long long)__builtin_amdgcn_s_memtime();
   double *li = linv + (size_t)(j / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
-    Lw[(size_t)(j + r) * ld + j + c] = (c <= r) ? sD[r][c] : 0.0;
-    li[t] = (c <= r) ? sLi[r][c] : 0.0;
+    Lw[(size_t)(j + r) * ld + j + c] = (c <= r) ? s.D[r][c] : 0.0;
+    li[t] = (c <= r) ? s.Li[r][c] : 0.0;
   }
-  if (tid == 0 && sFail) status[1] = status[3];  // status[3] = this try's stamp
+  if (tid == 0 && s.fail) status[1] = status[3];  // status[3] = this try's stamp
   if (tim && tid == 0) tim[15] = (long long)__builtin_amdgcn_s_memtime();
 }
 
@@ -228,6 +263,8 @@ __global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, d
 // one wave per tile: a 16x32x32 product with the stored inverse, 16 MFMAs.  k-slot pairing: MFMA
 // step t (0..7) pairs lane slot lk with k = 8 lk + t, so each lane fetches its operand values as
 // one 64-byte piece of its row (of C, and of L_dd^-1 whose rows are the columns of L_dd^-T).
+// (An f64 MFMA holds a SIMD's matrix pipe for 64 cycles on gfx950: four waves = four SIMDs per
+// workgroup, and the workgroups spread over the CUs.)
 __global__ __launch_bounds__(256) void k_cholg_trsm(double *Lw, int ld, int j, int nT, const double *linv) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -289,30 +326,29 @@ __device__ __forceinline__ d4 update_tile(const double *Lw, int ld, int j, int T
 // (one per wave) of the rest of the lower trailing triangle + the e_a tile row.
 __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, double *linv,
                                                       int *status) {
-  __shared__ double sD[GB][GB + 1], sLi[GB][GB + 1];
-  __shared__ double sCol[2][16], sInv[GB];
-  __shared__ int sFail;
+  __shared__ Factor32Lds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int T0 = (j + GB) / 16;  // first trailing tile row / column
   if (blockIdx.x == 0) {
-    if (tid == 0) sFail = 0;
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
     if (wave < 3) {
       const int TR = T0 + (wave > 0), TC = T0 + (wave > 1);
       const d4 c = update_tile(Lw, ld, j, TR, TC, li, lk);
 #pragma unroll
-      for (int r = 0; r < 4; r++) sD[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
+      for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
     }
     __syncthreads();
-    factor32(sD, sLi, sCol, sInv, &sFail, tid);
+    factor32(s, tid);
     const int jn = j + GB;
-    double *li = linv + (size_t)(jn / GB) * GB * GB;
+    double *lio = linv + (size_t)(jn / GB) * GB * GB;
     for (int t = tid; t < GB * GB; t += 256) {
       const int r = t / GB, c = t % GB;
-      Lw[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? sD[r][c] : 0.0;
-      li[t] = (c <= r) ? sLi[r][c] : 0.0;
+      Lw[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? s.D[r][c] : 0.0;
+      lio[t] = (c <= r) ? s.Li[r][c] : 0.0;
     }
-    if (tid == 0 && sFail) status[1] = status[3];
+    if (tid == 0 && s.fail) status[1] = status[3];
     return;
   }
   // tiles: the lower triangle of the M x M trailing tile grid (row-major: local row m, index
