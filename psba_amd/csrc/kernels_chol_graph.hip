@@ -4,9 +4,10 @@
 //
 // Same job and same data as kernels_chol.hip (which stays as the single-workgroup fallback):
 // S dpa = ea on the padded reduce buffer Lw[(n32+16)][n32], e_a riding along as row n32 so that
-// the forward solve is free; replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
+// the forward solve is free; the factor is collected in a second buffer of the same shape (Lx); replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
 // CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19).  The reference chains ~nA
-// device-enqueued launches of 3x3 blocks; here a panel is three steps:
+// device-enqueued launches of 3x3 blocks; here a panel is three steps (trsm and update fused
+// into one kernel, k_cholg_panel, for matrices of the size bundle adjustment usually has):
 //   diag    one wave factors the 32x32 diagonal block (4-column panels with rows in registers,
 //           rank-4 MFMA updates of register-resident tiles) while a second wave inverts the
 //           factor in its wake -- fused into the tail of the previous update;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void f32_post(int *flag, int v, int lane) {
   if (lane == 0) __hip_atomic_store((lds_int *)flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane) {
+__device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long long *tim = nullptr) {
   const int row = lane & 31;
   bool bad = false;
   d4 a, ap = {0, 0, 0, 0};
@@ -121,6 +122,7 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane) {
     }
     f32_post(&s.flag[0], q + 1, lane);
     ap = a;
+    if (tim && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
   }
   return bad;
 }
@@ -209,7 +211,7 @@ __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim
   const int lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, rc = lane >> 4;
   if (wave == 0) {
-    if (f32_pivot_wave(s, lane)) s.fail = 1;
+    if (f32_pivot_wave(s, lane, tim)) s.fail = 1;
     if (tim && lane == 0) tim[3] = (long long)__builtin_amdgcn_s_memtime();
   } else if (wave == 2) {
     f32_tile_wave(s, lane);
@@ -237,8 +239,8 @@ __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim
 
 // diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
 // alone only for the first panel.
-__global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, double *linv, int *status,
-                                                    long long *tim) {
+__global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx, int ld, int j, double *linv,
+                                                    int *status, long long *tim) {
   __shared__ Factor32Lds s;
   const int tid = threadIdx.x;
   if (tid < 4) s.flag[tid] = 0;
@@ -252,25 +254,20 @@ __global__ __launch_bounds__(256) void k_cholg_diag(double *Lw, int ld, int j, d
   double *li = linv + (size_t)(j / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
-    Lw[(size_t)(j + r) * ld + j + c] = (c <= r) ? s.D[r][c] : 0.0;
+    Lx[(size_t)(j + r) * ld + j + c] = (c <= r) ? s.D[r][c] : 0.0;
     li[t] = (c <= r) ? s.Li[r][c] : 0.0;
   }
   if (tid == 0 && s.fail) status[1] = status[3];  // status[3] = this try's stamp
   if (tim && tid == 0) tim[15] = (long long)__builtin_amdgcn_s_memtime();
 }
 
-// trsm: X = C L_dd^-T for the 16-row tiles below the panel's diagonal block (incl. the e_a tile),
-// one wave per tile: a 16x32x32 product with the stored inverse, 16 MFMAs.  k-slot pairing: MFMA
-// step t (0..7) pairs lane slot lk with k = 8 lk + t, so each lane fetches its operand values as
-// one 64-byte piece of its row (of C, and of L_dd^-1 whose rows are the columns of L_dd^-T).
-// (An f64 MFMA holds a SIMD's matrix pipe for 64 cycles on gfx950: four waves = four SIMDs per
-// workgroup, and the workgroups spread over the CUs.)
-__global__ __launch_bounds__(256) void k_cholg_trsm(double *Lw, int ld, int j, int nT, const double *linv) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const int T = (j + GB) / 16 + blockIdx.x * 4 + wave;
-  if (T >= nT) return;
-  const double *Li = linv + (size_t)(j / GB) * GB * GB;
+// X = C L_dd^-T for one 16-row tile T below the diagonal block of the panel at column j, by one
+// wave: a 16x32x32 product with the stored inverse, 16 MFMAs, result in the accumulator layout
+// (xl: columns 0..15, xr: 16..31).  k-slot pairing: MFMA step t (0..7) pairs lane slot lk with
+// k = 8 lk + t, so each lane fetches its operand values as one 64-byte piece of its row (of C,
+// and of L_dd^-1 whose rows are the columns of L_dd^-T).
+__device__ __forceinline__ void trsm_tile(const double *Lw, int ld, int j, int T, const double *Li, int li,
+                                          int lk, d4 &xl, d4 &xr) {
   const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * T + li) * ld + j + 8 * lk);
   const double4 *b0p = reinterpret_cast<const double4 *>(Li + (size_t)li * GB + 8 * lk);
   const double4 *b1p = reinterpret_cast<const double4 *>(Li + (size_t)(16 + li) * GB + 8 * lk);
@@ -292,73 +289,67 @@ __global__ __launch_bounds__(256) void k_cholg_trsm(double *Lw, int ld, int j, i
   y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.z, q1.z, y0, 0, 0, 0);
   x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.w, p1.w, x1, 0, 0, 0);
   y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.w, q1.w, y1, 0, 0, 0);
+  xl = x0 + x1;
+  xr = y0 + y1;
+}
+
+__device__ __forceinline__ void store_x_tile(double *Lx, int ld, int j, int T, int li, int lk, const d4 &xl,
+                                             const d4 &xr) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li] = x0[r] + x1[r];
-    Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 + li] = y0[r] + y1[r];
+    Lx[(size_t)(16 * T + lk + 4 * r) * ld + j + li] = xl[r];
+    Lx[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 + li] = xr[r];
   }
 }
 
-// one 16x16 tile of the trailing update: C[TR][TC] -= X[TR rows][j..j+31] X[TC rows][j..j+31]^T.
-// k-slot pairing: MFMA step t (0..7) pairs lane slot lk with column j + 8 lk + t, so each lane
-// fetches its eight operand values as one 64-byte piece of its row.
-__device__ __forceinline__ d4 update_tile(const double *Lw, int ld, int j, int TR, int TC, int li,
-                                          int lk) {
-  const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * TR + li) * ld + j + 8 * lk);
-  const double4 *bp = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * TC + li) * ld + j + 8 * lk);
-  const double4 a0 = ap[0], a1 = ap[1], b0 = bp[0], b1 = bp[1];
-  d4 c0, c1 = {0, 0, 0, 0};
+// trsm as a kernel of its own: one wave per 16-row tile below the panel's diagonal block (incl.
+// the e_a tile), result into the factor buffer Lx.  Used for the last panel, and for every
+// panel when the matrix is too large for the fused panel kernel to pay (see enqueue_chain).
+__global__ __launch_bounds__(256) void k_cholg_trsm(const double *Lw, double *Lx, int ld, int j, int nT,
+                                                    const double *linv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T = (j + GB) / 16 + blockIdx.x * 4 + wave;
+  if (T >= nT) return;
+  d4 xl, xr;
+  trsm_tile(Lw, ld, j, T, linv + (size_t)(j / GB) * GB * GB, li, lk, xl, xr);
+  store_x_tile(Lx, ld, j, T, li, lk, xl, xr);
+}
+
+// eight operand values (k = 8 lk .. 8 lk + 7 of row li) as MFMA steps
+struct Row8 {
+  double v[8];
+};
+__device__ __forceinline__ Row8 load_row8(const double *p) {
+  const double4 a = reinterpret_cast<const double4 *>(p)[0], b = reinterpret_cast<const double4 *>(p)[1];
+  return {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ d4 update_mfma(d4 c0, const Row8 &a, const Row8 &b) {
+  d4 c1 = {0, 0, 0, 0};
 #pragma unroll
-  for (int r = 0; r < 4; r++) c0[r] = Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li];
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.x, b0.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.y, b0.y, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.z, b0.z, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.w, b0.w, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.x, b1.x, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.y, b1.y, c1, 0, 0, 0);
-  c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.z, b1.z, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.w, b1.w, c1, 0, 0, 0);
+  for (int t = 0; t < 8; t += 2) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.v[t], b.v[t], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.v[t + 1], b.v[t + 1], c1, 0, 0, 0);
+  }
   return c0 + c1;
 }
-
-// update: workgroup 0 owns the three tiles of the next diagonal block and factors it once they
-// are updated (the "diag" step of the next panel); every other workgroup owns four tiles
-// (one per wave) of the rest of the lower trailing triangle + the e_a tile row.
-__global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j, int nT, double *linv,
-                                                      int *status) {
-  __shared__ Factor32Lds s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const int T0 = (j + GB) / 16;  // first trailing tile row / column
-  if (blockIdx.x == 0) {
-    if (tid < 4) s.flag[tid] = 0;
-    if (tid == 4) s.fail = 0;
-    if (wave < 3) {
-      const int TR = T0 + (wave > 0), TC = T0 + (wave > 1);
-      const d4 c = update_tile(Lw, ld, j, TR, TC, li, lk);
+__device__ __forceinline__ d4 load_c_tile(const double *Lw, int ld, int TR, int TC, int li, int lk) {
+  d4 c;
 #pragma unroll
-      for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
-    }
-    __syncthreads();
-    factor32(s, tid);
-    const int jn = j + GB;
-    double *lio = linv + (size_t)(jn / GB) * GB * GB;
-    for (int t = tid; t < GB * GB; t += 256) {
-      const int r = t / GB, c = t % GB;
-      Lw[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? s.D[r][c] : 0.0;
-      lio[t] = (c <= r) ? s.Li[r][c] : 0.0;
-    }
-    if (tid == 0 && s.fail) status[1] = status[3];
-    return;
-  }
-  // tiles: the lower triangle of the M x M trailing tile grid (row-major: local row m, index
-  // m (m + 1) / 2 + local column; the first three indices (0,0), (1,0), (1,1) belong to
-  // workgroup 0), followed by the M tiles of the e_a tile row (tile row nT - 1)
-  const long long idx = (long long)(blockIdx.x - 1) * 4 + wave + 3;
+  for (int r = 0; r < 4; r++) c[r] = Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li];
+  return c;
+}
+__device__ __forceinline__ void store_c_tile(double *Lw, int ld, int TR, int TC, int li, int lk, const d4 &c) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li] = c[r];
+}
+// tile index -> (TR, TC): the lower triangle of the M x M trailing tile grid (row-major: local
+// row m, index m (m + 1) / 2 + local column; the first three indices (0,0), (1,0), (1,1) belong
+// to workgroup 0), followed by the M tiles of the e_a tile row (tile row nT - 1)
+__device__ __forceinline__ bool tile_of_index(long long idx, int T0, int nT, int &TR, int &TC) {
   const long long M = (nT - 1) - T0;
   const long long ntri = M * (M + 1) / 2;
-  if (idx >= ntri + M) return;
-  int TR, TC;
+  if (idx >= ntri + M) return false;
   if (idx < ntri) {
     int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
     while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
@@ -369,16 +360,130 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, int ld, int j,
     TR = nT - 1;
     TC = T0 + (int)(idx - ntri);
   }
-  const d4 c = update_tile(Lw, ld, j, TR, TC, li, lk);
+  return true;
+}
+
+// one 16x16 tile of the trailing update: C[TR][TC] -= X[TR rows][j..j+31] X[TC rows][j..j+31]^T,
+// X read from the factor buffer.  k-slot pairing: MFMA step t (0..7) pairs lane slot lk with
+// column j + 8 lk + t, so each lane fetches its eight operand values as one 64-byte piece of its row.
+__device__ __forceinline__ d4 update_tile(const double *Lw, const double *Lx, int ld, int j, int TR, int TC,
+                                          int li, int lk) {
+  const Row8 a = load_row8(Lx + (size_t)(16 * TR + li) * ld + j + 8 * lk);
+  const Row8 b = load_row8(Lx + (size_t)(16 * TC + li) * ld + j + 8 * lk);
+  return update_mfma(load_c_tile(Lw, ld, TR, TC, li, lk), a, b);
+}
+
+// workgroup 0's tail: factor the next diagonal block (in s.D) and store factor + inverse
+__device__ __forceinline__ void factor_next(Factor32Lds &s, double *Lx, int ld, int jn, double *linv,
+                                            int *status, int tid) {
+  factor32(s, tid);
+  double *lio = linv + (size_t)(jn / GB) * GB * GB;
+  for (int t = tid; t < GB * GB; t += 256) {
+    const int r = t / GB, c = t % GB;
+    Lx[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? s.D[r][c] : 0.0;
+    lio[t] = (c <= r) ? s.Li[r][c] : 0.0;
+  }
+  if (tid == 0 && s.fail) status[1] = status[3];
+}
+
+// update (unfused chain): workgroup 0 owns the three tiles of the next diagonal block and factors
+// it once they are updated (the "diag" step of the next panel); every other workgroup owns four
+// tiles (one per wave) of the rest of the lower trailing triangle + the e_a tile row.
+__global__ __launch_bounds__(256) void k_cholg_update(double *Lw, double *Lx, int ld, int j, int nT,
+                                                      double *linv, int *status) {
+  __shared__ Factor32Lds s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T0 = (j + GB) / 16;  // first trailing tile row / column
+  if (blockIdx.x == 0) {
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
+    if (wave < 3) {
+      const int TR = T0 + (wave > 0), TC = T0 + (wave > 1);
+      const d4 c = update_tile(Lw, Lx, ld, j, TR, TC, li, lk);
 #pragma unroll
-  for (int r = 0; r < 4; r++) Lw[(size_t)(16 * TR + lk + 4 * r) * ld + 16 * TC + li] = c[r];
+      for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
+    }
+    __syncthreads();
+    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    return;
+  }
+  int TR, TC;
+  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, TR, TC)) return;
+  store_c_tile(Lw, ld, TR, TC, li, lk, update_tile(Lw, Lx, ld, j, TR, TC, li, lk));
+}
+
+// panel (fused chain): trsm + update of the panel at column j in ONE kernel.  Every wave
+// computes the two 16-row pieces of X = C L_dd^-T its tile needs itself (32 MFMAs instead of
+// reading them: the panel is small and there are more idle SIMDs than tiles), turns them into
+// MFMA operands through a wave-private LDS scratch and updates its tile (8 MFMAs).  The waves of
+// the first trailing tile column also store their X piece into the factor buffer.  Workgroup 0
+// does the same for the next diagonal block and then factors it.  Against trsm and update as
+// two kernels this saves a kernel boundary and a global round trip of X per panel; the redundant
+// MFMA work runs in the shadow of workgroup 0's serial factorization.
+constexpr int XS = 34;  // row stride of the X scratch: 16-byte aligned rows, conflict-free pieces
+__global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT,
+                                                     double *linv, int *status) {
+  __shared__ Factor32Lds s;
+  __shared__ double sX[4][2][16][XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T0 = (j + GB) / 16;  // first trailing tile row / column
+  const double *Li = linv + (size_t)(j / GB) * GB * GB;
+  if (blockIdx.x == 0) {
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
+    if (wave < 2) {  // X of the two tile rows of the next diagonal block
+      d4 xl, xr;
+      trsm_tile(Lw, ld, j, T0 + wave, Li, li, lk, xl, xr);
+      store_x_tile(Lx, ld, j, T0 + wave, li, lk, xl, xr);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        sX[0][wave][lk + 4 * r][li] = xl[r];
+        sX[0][wave][lk + 4 * r][16 + li] = xr[r];
+      }
+    }
+    __syncthreads();
+    if (wave < 3) {
+      const int tr = (wave > 0), tc = (wave > 1);
+      const Row8 a = load_row8(&sX[0][tr][li][8 * lk]), b = load_row8(&sX[0][tc][li][8 * lk]);
+      const d4 c = update_mfma(load_c_tile(Lw, ld, T0 + tr, T0 + tc, li, lk), a, b);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s.D[16 * tr + lk + 4 * r][16 * tc + li] = c[r];
+    }
+    __syncthreads();
+    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    return;
+  }
+  int TR, TC;
+  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, TR, TC)) return;
+  d4 c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
+  d4 xl, xr;
+  trsm_tile(Lw, ld, j, TR, Li, li, lk, xl, xr);
+  if (TC == T0) store_x_tile(Lx, ld, j, TR, li, lk, xl, xr);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    sX[wave][0][lk + 4 * r][li] = xl[r];
+    sX[wave][0][lk + 4 * r][16 + li] = xr[r];
+  }
+  if (TC != TR) {
+    trsm_tile(Lw, ld, j, TC, Li, li, lk, xl, xr);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sX[wave][1][lk + 4 * r][li] = xl[r];
+      sX[wave][1][lk + 4 * r][16 + li] = xr[r];
+    }
+  }
+  const Row8 a = load_row8(&sX[wave][0][li][8 * lk]);
+  const Row8 b = load_row8(&sX[wave][TC != TR][li][8 * lk]);
+  store_c_tile(Lw, ld, TR, TC, li, lk, update_mfma(c, a, b));
 }
 
 // backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 32:
 // x_J = L_dd^-T y_J is a 32x32 mat-vec with the stored inverse (no dependent chain), then all
 // threads apply y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update do not depend on x
 // and are fetched before the mat-vec so that their latency overlaps it.
-__global__ __launch_bounds__(512) void k_cholg_backward(double *Lw, int ld, int n, int n32, double *x,
+__global__ __launch_bounds__(512) void k_cholg_backward(double *Lw /* the factor buffer */, int ld, int n, int n32, double *x,
                                                        const double *linv, int *status) {
   __shared__ double sX[GB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -443,21 +548,27 @@ __global__ __launch_bounds__(512) void k_cholg_backward(double *Lw, int ld, int 
 
 static void enqueue_chain(psba_ctx *h, hipStream_t s) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
-  double *Lw = h->red, *linv = h->chol_ws;
-  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, ld, 0, linv, h->status, h->chol_tim);
+  double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
+  // fused panel kernel while a panel's tiles (one wave each, 5x the MFMA work) still fit on the
+  // chip's 1024 SIMDs at once; beyond that the redundant trsm work is no longer free
+  const long long M0 = (nT - 1) - GB / 16;
+  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 1024;
+  hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   for (int j = 0; j < n32; j += GB) {
-    const int tilesBelow = nT - (j + GB) / 16;  // 16-row tiles below the panel incl. the e_a tile
-    hipLaunchKernelGGL(k_cholg_trsm, dim3((tilesBelow + 3) / 4), dim3(256), 0, s, Lw, ld, j, nT, linv);
-    if (j + GB < n32) {
-      const long long M = (nT - 1) - (j + GB) / 16;
-      const long long tiles = M * (M + 1) / 2 + M - 3;
-      const int grid = 1 + (int)((tiles + 3) / 4);
-      hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, ld, j, nT, linv, h->status);
+    const bool last = j + GB >= n32;
+    const long long M = (nT - 1) - (j + GB) / 16;
+    const int grid = 1 + (int)((M * (M + 1) / 2 + M - 3 + 3) / 4);
+    if (last || !fused) {
+      const int tilesBelow = nT - (j + GB) / 16;  // 16-row tiles below the panel incl. the e_a tile
+      hipLaunchKernelGGL(k_cholg_trsm, dim3((tilesBelow + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv);
+      if (!last) hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
+    } else {
+      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
     }
   }
   int thr = (n32 + 63) / 64 * 64;
   if (thr > 512) thr = 512;
-  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lw, ld, h->d.nA, n32, h->dp, linv,
+  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
                      h->status);
 }
 

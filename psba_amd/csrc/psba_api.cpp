@@ -109,6 +109,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->chol_ws);
+  dev_free(h->chol_L);
   dev_free(h->dbg_ex);
   dev_free(h->dbg_JA);
   dev_free(h->dbg_JB);
@@ -260,6 +261,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
+  TRY(dev_alloc(h, &h->chol_L, (size_t)(h->n32 + 16) * h->n32));
+  PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
   // ---- K2's static schedule (camera-row groups, workgroups, conflict-free item rows) ----
   {

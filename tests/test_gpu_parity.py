@@ -386,3 +386,25 @@ def test_single_workgroup_cholesky_fallback(problems, monkeypatch):
     assert rc == 0
     close(dpa, dp[: o.nA], 1e-9, "dpa")
     h.close()
+
+
+def test_unfused_panel_chain(problems, monkeypatch):
+    """PSBA_CHOL_UNFUSED=1 selects trsm and update as two kernels per panel (the path matrices
+    too large for the fused panel kernel take); it must agree with the oracle as well."""
+    import psba_amd
+    monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")
+    prob = problems["54cams"]
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, _ = o.solve(lin, sch)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    h.compute_S()
+    rc, dpa = h.SPDinv_matVec()
+    assert rc == 0
+    close(dpa, dp[: o.nA], 1e-9, "dpa")
+    h.close()
