@@ -4,7 +4,13 @@
 //
 // Same job and same data as kernels_chol.hip (which stays as the single-workgroup fallback):
 // S dpa = ea on the padded reduce buffer Lw[(n32+16)][n32], e_a riding along as row n32 so that
-// the forward solve is free; the factor is collected in a second buffer of the same shape (Lx); replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
+// the forward solve is free; the factor is collected in a second buffer of the same shape (Lx).
+// The backward solve rides along too: n32 rows holding the identity below the e_a tile go
+// through the same trsm / update steps and end up as L^-T (row i = e_i^T L^-T), so dpa is one
+// parallel mat-vec L^-T y at the end instead of a strictly sequential substitution that a
+// single CU has to feed from HBM (measured ~20 us of the old 120).  The identity rows cost
+// no memory traffic before they are touched: a tile row e is generated in registers until the
+// panel that contains column block e, and the tiles left of the diagonal stay zero; replaces SPDinv + matVec_mul (reference PSBA/cl_spdinv.cpp:18-204,
 // CL_files/SPD_inv.cl:20-411, PSBA/cl_linearalg.cpp:19).  The reference chains ~nA
 // device-enqueued launches of 3x3 blocks; here a panel is three steps (trsm and update fused
 // into one kernel, k_cholg_panel, for matrices of the size bundle adjustment usually has):
@@ -261,17 +267,28 @@ __global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx
   if (tim && tid == 0) tim[15] = (long long)__builtin_amdgcn_s_memtime();
 }
 
-// X = C L_dd^-T for one 16-row tile T below the diagonal block of the panel at column j, by one
-// wave: a 16x32x32 product with the stored inverse, 16 MFMAs, result in the accumulator layout
+// X = C L_dd^-T for one 16-row tile T below the diagonal block of the panel at column j (nT and
+// above: the identity rows, see the top of the file), by one wave: a 16x32x32 product with the stored inverse, 16 MFMAs, result in the accumulator layout
 // (xl: columns 0..15, xr: 16..31).  k-slot pairing: MFMA step t (0..7) pairs lane slot lk with
 // k = 8 lk + t, so each lane fetches its operand values as one 64-byte piece of its row (of C,
 // and of L_dd^-1 whose rows are the columns of L_dd^-T).
-__device__ __forceinline__ void trsm_tile(const double *Lw, int ld, int j, int T, const double *Li, int li,
-                                          int lk, d4 &xl, d4 &xr) {
-  const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * T + li) * ld + j + 8 * lk);
+__device__ __forceinline__ void trsm_tile(const double *Lw, int ld, int j, int T, int nT, const double *Li,
+                                          int li, int lk, d4 &xl, d4 &xr) {
   const double4 *b0p = reinterpret_cast<const double4 *>(Li + (size_t)li * GB + 8 * lk);
   const double4 *b1p = reinterpret_cast<const double4 *>(Li + (size_t)(16 + li) * GB + 8 * lk);
-  const double4 a0 = ap[0], a1 = ap[1], p0 = b0p[0], p1 = b0p[1], q0 = b1p[0], q1 = b1p[1];
+  const double4 p0 = b0p[0], p1 = b0p[1], q0 = b1p[0], q1 = b1p[1];
+  double4 a0, a1;
+  const int e = T - nT;  // >= 0: identity tile row e (rows 16 e .. of the identity)
+  if (e >= j / 16) {
+    // not touched by any panel yet: its piece of this panel is [I 0] or [0 I] -- generate it
+    const int k1 = 16 * (e - j / 16) + li - 8 * lk;  // position of the 1 in this lane's piece
+    a0 = make_double4(k1 == 0, k1 == 1, k1 == 2, k1 == 3);
+    a1 = make_double4(k1 == 4, k1 == 5, k1 == 6, k1 == 7);
+  } else {
+    const double4 *ap = reinterpret_cast<const double4 *>(Lw + (size_t)(16 * T + li) * ld + j + 8 * lk);
+    a0 = ap[0];
+    a1 = ap[1];
+  }
   d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
   x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, p0.x, x0, 0, 0, 0);
   y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, q0.x, y0, 0, 0, 0);
@@ -306,13 +323,13 @@ __device__ __forceinline__ void store_x_tile(double *Lx, int ld, int j, int T, i
 // the e_a tile), result into the factor buffer Lx.  Used for the last panel, and for every
 // panel when the matrix is too large for the fused panel kernel to pay (see enqueue_chain).
 __global__ __launch_bounds__(256) void k_cholg_trsm(const double *Lw, double *Lx, int ld, int j, int nT,
-                                                    const double *linv) {
+                                                    int nTall, const double *linv) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int T = (j + GB) / 16 + blockIdx.x * 4 + wave;
-  if (T >= nT) return;
+  if (T >= nTall) return;  // nTall = nT, or nT + n32 / 16 when the identity rows ride along
   d4 xl, xr;
-  trsm_tile(Lw, ld, j, T, linv + (size_t)(j / GB) * GB * GB, li, lk, xl, xr);
+  trsm_tile(Lw, ld, j, T, nT, linv + (size_t)(j / GB) * GB * GB, li, lk, xl, xr);
   store_x_tile(Lx, ld, j, T, li, lk, xl, xr);
 }
 
@@ -345,20 +362,30 @@ __device__ __forceinline__ void store_c_tile(double *Lw, int ld, int TR, int TC,
 }
 // tile index -> (TR, TC): the lower triangle of the M x M trailing tile grid (row-major: local
 // row m, index m (m + 1) / 2 + local column; the first three indices (0,0), (1,0), (1,1) belong
-// to workgroup 0), followed by the M tiles of the e_a tile row (tile row nT - 1)
-__device__ __forceinline__ bool tile_of_index(long long idx, int T0, int nT, int &TR, int &TC) {
+// to workgroup 0), followed by the M tiles of the e_a tile row (tile row nT - 1) and, when the
+// identity rows ride along (nId > 0: the identity tile rows 0 .. nId - 1 this panel reaches),
+// their M tiles each (tile row nT + e).  fresh: an identity tile not touched before, i.e. zero.
+__device__ __forceinline__ bool tile_of_index(long long idx, int T0, int nT, int nId, int &TR, int &TC,
+                                              bool &fresh) {
   const long long M = (nT - 1) - T0;
   const long long ntri = M * (M + 1) / 2;
-  if (idx >= ntri + M) return false;
+  fresh = false;
+  if (idx >= ntri + M + nId * M) return false;
   if (idx < ntri) {
     int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
     while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
     while ((long long)m * (m + 1) / 2 > idx) m--;
     TR = T0 + m;
     TC = T0 + (int)(idx - (long long)m * (m + 1) / 2);
-  } else {
+  } else if (idx < ntri + M) {
     TR = nT - 1;
     TC = T0 + (int)(idx - ntri);
+  } else {
+    const long long k = idx - ntri - M;
+    const int e = (int)(k / M);
+    TR = nT + e;
+    TC = T0 + (int)(k % M);
+    fresh = e >= T0 - 2;  // the two tile rows of this panel's own column block
   }
   return true;
 }
@@ -409,7 +436,8 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, double *Lx, in
     return;
   }
   int TR, TC;
-  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, TR, TC)) return;
+  bool fresh;
+  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, 0, TR, TC, fresh)) return;
   store_c_tile(Lw, ld, TR, TC, li, lk, update_tile(Lw, Lx, ld, j, TR, TC, li, lk));
 }
 
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     if (tid == 4) s.fail = 0;
     if (wave < 2) {  // X of the two tile rows of the next diagonal block
       d4 xl, xr;
-      trsm_tile(Lw, ld, j, T0 + wave, Li, li, lk, xl, xr);
+      trsm_tile(Lw, ld, j, T0 + wave, nT, Li, li, lk, xl, xr);
       store_x_tile(Lx, ld, j, T0 + wave, li, lk, xl, xr);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -456,10 +484,12 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     return;
   }
   int TR, TC;
-  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, TR, TC)) return;
-  d4 c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
+  bool fresh;
+  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, T0, TR, TC, fresh)) return;
+  d4 c = {0, 0, 0, 0};
+  if (!fresh) c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
   d4 xl, xr;
-  trsm_tile(Lw, ld, j, TR, Li, li, lk, xl, xr);
+  trsm_tile(Lw, ld, j, TR, nT, Li, li, lk, xl, xr);
   if (TC == T0) store_x_tile(Lx, ld, j, TR, li, lk, xl, xr);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -467,7 +497,7 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     sX[wave][0][lk + 4 * r][16 + li] = xr[r];
   }
   if (TC != TR) {
-    trsm_tile(Lw, ld, j, TC, Li, li, lk, xl, xr);
+    trsm_tile(Lw, ld, j, TC, nT, Li, li, lk, xl, xr);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       sX[wave][1][lk + 4 * r][li] = xl[r];
@@ -546,30 +576,69 @@ __global__ __launch_bounds__(512) void k_cholg_backward(double *Lw /* the factor
   if (bad) status[1] = status[3];
 }
 
+// dpa = L^-T y: the identity rows of the factor buffer now hold L^-T (row i = e_i^T L^-T, upper
+// triangular), y = L^-1 e_a sits in row n32.  One wave per row, all loads of a lane issued at
+// once (n32 <= 640 on this path: at most ten 64-column strides).
+__global__ __launch_bounds__(256) void k_cholg_solve(const double *Lx, int ld, int n, int n32, double *x,
+                                                    int *status) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const double *y = Lx + (size_t)n32 * ld;
+  const double *z = Lx + (size_t)(n32 + 16 + i) * ld;
+  double zv[10], yv[10];
+#pragma unroll
+  for (int m = 0; m < 10; m++) {
+    const int c = lane + 64 * m;
+    const bool on = c < n32 && c >= (i & ~15);  // left of the diagonal tile: zeros, never written
+    zv[m] = on ? z[c] : 0.0;
+    yv[m] = on ? y[c] : 0.0;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int m = 0; m < 10; m++) acc += zv[m] * yv[m];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    x[i] = acc;
+    if (!isfinite(acc)) status[1] = status[3];
+  }
+}
+
 static void enqueue_chain(psba_ctx *h, hipStream_t s) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
   double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
-  // fused panel kernel while a panel's tiles (one wave each, 5x the MFMA work) still fit on the
-  // chip's 1024 SIMDs at once; beyond that the redundant trsm work is no longer free
+  // fused panel kernel (with the identity rows riding along) while a panel's tiles (one wave
+  // each, 5x the MFMA work) still fit on the chip's 1024 SIMDs at once; beyond that the
+  // redundant work is no longer free: two kernels per panel and a sequential backward solve
   const long long M0 = (nT - 1) - GB / 16;
-  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 1024;
+  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 640;
   hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   for (int j = 0; j < n32; j += GB) {
     const bool last = j + GB >= n32;
-    const long long M = (nT - 1) - (j + GB) / 16;
-    const int grid = 1 + (int)((M * (M + 1) / 2 + M - 3 + 3) / 4);
+    const int T0 = (j + GB) / 16;
+    const long long M = (nT - 1) - T0;
     if (last || !fused) {
-      const int tilesBelow = nT - (j + GB) / 16;  // 16-row tiles below the panel incl. the e_a tile
-      hipLaunchKernelGGL(k_cholg_trsm, dim3((tilesBelow + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv);
-      if (!last) hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
+      // 16-row tiles below the panel incl. the e_a tile (+ all identity tile rows at the end)
+      const int nTall = (last && fused) ? nT + n32 / 16 : nT;
+      hipLaunchKernelGGL(k_cholg_trsm, dim3((nTall - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nTall, linv);
+      if (!last) {
+        const int grid = 1 + (int)((M * (M + 1) / 2 + M - 3 + 3) / 4);
+        hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
+      }
     } else {
+      const int grid = 1 + (int)((M * (M + 1) / 2 + M + (long long)T0 * M - 3 + 3) / 4);
       hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
     }
   }
-  int thr = (n32 + 63) / 64 * 64;
-  if (thr > 512) thr = 512;
-  hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
-                     h->status);
+  if (fused) {
+    hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lx, ld, h->d.nA, n32, h->dp,
+                       h->status);
+  } else {
+    int thr = (n32 + 63) / 64 * 64;
+    if (thr > 512) thr = 512;
+    hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
+                       h->status);
+  }
 }
 
 int launch_chol_graph(psba_ctx *h) {

@@ -257,12 +257,14 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
   TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
   h->n32 = (d.nA + 31) / 32 * 32;
-  TRY(dev_alloc(h, &h->red, (size_t)(h->n32 + 16) * h->n32));
-  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
+  // rows [0, n32 + 16) are the reduce buffer proper; n32 more rows below it are the working
+  // space of the identity rows the panel chain carries along (kernels_chol_graph.hip)
+  TRY(dev_alloc(h, &h->red, (size_t)(2 * h->n32 + 16) * h->n32));
+  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(2 * h->n32 + 16) * h->n32, h->stream));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
-  TRY(dev_alloc(h, &h->chol_L, (size_t)(h->n32 + 16) * h->n32));
-  PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * (size_t)(h->n32 + 16) * h->n32, h->stream));
+  TRY(dev_alloc(h, &h->chol_L, (size_t)(2 * h->n32 + 16) * h->n32));
+  PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * (size_t)(2 * h->n32 + 16) * h->n32, h->stream));
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
   // ---- K2's static schedule (camera-row groups, workgroups, conflict-free item rows) ----
   {

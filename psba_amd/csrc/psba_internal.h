@@ -101,7 +101,7 @@ struct psba_ctx {
   int chol_graph_n32 = 0;
   double *chol_graph_red = nullptr;
   long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
-  double *chol_L = nullptr;     // [(n32+16)][n32] the Cholesky factor (+ forward-solved e_a row) of the panel chain
+  double *chol_L = nullptr;     // [(2 n32+16)][n32] panel chain: the Cholesky factor | forward-solved e_a row | L^-T
   double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
   double *scal = nullptr;       // [NSCAL]
   // [4] generation stamps, never zeroed: [0] == try_id <=> some V_i singular in this try,
