@@ -52,24 +52,31 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // The serial part of the whole solve is the chain of nA pivots, so everything that is not a
 // pivot step is moved off the wave that runs the chain:
 //   wave 0  pivot wave: panels of four columns with lane = row and the four columns in
-//           registers.  Per column the dependent chain is readlane(pivot) -> rsq + two Newton
-//           steps -> scale -> <= 3 (readlane, fma).  The panel's own rank-4 update of the NEXT
-//           panel's columns is applied here in the row layout (16 fma with readlane scalars);
+//           registers, eliminated without square roots (A'[i][j] = A[i][j] - A[i][k] A[j][k] / d_k;
+//           the Cholesky factor is these columns scaled by 1 / sqrt(d_k), which nobody on the
+//           chain needs).  Per pivot the dependent chain is readlane(pivot) -> rcp + one cubic
+//           correction (3 fma) -> column / d -> next pivot (1 fma, in its own lane).  The panel's
+//           rank-4 update of the NEXT panel's columns is applied here in the row layout
+//           (16 fma with readlane scalars);
 //   wave 2  tile wave: keeps the trailing matrix as three 16x16 tiles in the MFMA accumulator
 //           layout, applies each published panel as one v_mfma_f64_16x16x4_f64 per tile and
 //           stages the columns of panel p+2 (updates <= p applied) for the pivot wave;
-//   wave 1  inverse of the upper-left 16x16 of the factor, column c per lane, rows following
-//           the panels as they are published; then T = L21 inv(L11) by MFMA;
-//   wave 3  inverse of the lower-right 16x16 the same way, then inv21 = -inv(L22) T by MFMA.
+//   wave 1  inverse of the upper-left 16x16 of the eliminated columns, column c per lane, rows
+//           following the panels as they are published; then T = D21 inv(D11) by MFMA;
+//   wave 3  inverse of the lower-right 16x16 the same way, then inv21 = -inv(D22) T by MFMA.
+// The square roots are taken once at the end, 32 lanes in parallel: L^-1 = diag(sqrt d) D^-1.
 // Progress is published through LDS words (one writer each): sFlag[0] = panels in sD,
 // sFlag[1] = panels staged by the tile wave (+2), sFlag[2] = tile wave has loaded its tiles,
 // sFlag[3] = T is in LDS.  A wave's LDS operations complete in order, so data written before a
 // flag is visible to whoever sees the flag.  No wave exits early, so every wait ends.
 struct Factor32Lds {
-  double D[GB][GB + 1];   // in: the block (lower triangle valid); out: its factor, zeros above
-  double Li[GB][GB + 1];  // out: inverse of the factor (lower triangle valid)
+  // in: the block (lower triangle valid); out: the columns of its LDL^T-style elimination,
+  // D[r][c] = L[r][c] sqrt(d_c) with d_c = D[c][c] the pivots (zeros above the diagonal)
+  double D[GB][GB + 1];
+  double Li[GB][GB + 1];  // out: inverse of D as a matrix (lower triangle valid)
   double next[2][GB][4];  // staged panels
-  double inv[GB];         // 1 / L[r][r]
+  double rinv[GB];        // 1 / d_c
+  double sq[GB];          // sqrt(d_c): L = D diag(1 / sq), L^-1 = diag(sq) Li
   int flag[4];
   int fail;
 };
@@ -84,10 +91,18 @@ __device__ __forceinline__ void f32_post(int *flag, int v, int lane) {
   if (lane == 0) __hip_atomic_store((lds_int *)flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// 1 / d to full precision: v_rcp_f64 is good to ~2^-24, one cubic step (e + e^2) finishes it
+__device__ __forceinline__ double recip_cubic(double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, r0, 1.0);
+  const double p = __builtin_fma(e, e, e);
+  return __builtin_fma(r0, p, r0);
+}
+
 __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long long *tim = nullptr) {
   const int row = lane & 31;
   bool bad = false;
-  d4 a, ap = {0, 0, 0, 0};
+  d4 a, ap = {0, 0, 0, 0}, tp = {0, 0, 0, 0};  // this panel's columns; the previous one's, and those / d
 #pragma clang loop unroll(full)
   for (int q = 0; q < 8; q++) {
     const int j0 = 4 * q;
@@ -108,18 +123,25 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
 #pragma clang loop unroll(full)
       for (int k2 = 0; k2 < 4; k2++)
 #pragma clang loop unroll(full)
-        for (int k = 0; k < 4; k++) a[k2] -= ap[k] * readlane_f64g(ap[k], j0 + k2);
+        for (int k = 0; k < 4; k++) a[k2] -= tp[k] * readlane_f64g(ap[k], j0 + k2);
     }
+    d4 t;
+    double d = readlane_f64g(a[0], j0);
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; k++) {
-      const double d = readlane_f64g(a[k], j0 + k);
       bad |= !(d > 0.0) || !(d < 1.7e308);
-      const double y = rsqrt_nr(d);
-      const double l = a[k] * y;  // the pivot row gets d / sqrt(d)
-      a[k] = l;
+      const double r = recip_cubic(d);
+      t[k] = a[k] * r;
+      if (lane == 0) {
+        s.rinv[j0 + k] = r;
+        s.sq[j0 + k] = d;  // the square root is taken at the end, off the chain
+      }
+      if (k < 3) {
+        // the next pivot, in its own lane: no broadcast between two pivots but the pivot itself
+        d = readlane_f64g(__builtin_fma(-t[k], a[k], a[k + 1]), j0 + k + 1);
 #pragma clang loop unroll(full)
-      for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= l * readlane_f64g(l, j0 + k2);
-      if (lane == 0) s.inv[j0 + k] = y;
+        for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= t[k] * readlane_f64g(a[k], j0 + k2);
+      }
     }
     if (q == 0) f32_wait(&s.flag[2], 1);  // the tile wave reads the original block first
     if (lane < 32) {
@@ -128,6 +150,7 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
     }
     f32_post(&s.flag[0], q + 1, lane);
     ap = a;
+    tp = t;
     if (tim && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
   }
   return bad;
@@ -148,13 +171,14 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
   for (int p = 0; p < 6; p++) {  // panel p+2 <= 7 is the last one to stage
     const int j0 = 4 * p;
     f32_wait(&s.flag[0], p + 1);
-    const double a1 = s.D[16 + col][j0 + rc];
+    // rank-4 update A -= (D / d) D^T: one operand scaled by 1 / d_k, k = this lane's k slot
+    const double a1 = s.D[16 + col][j0 + rc], nr = -s.rinv[j0 + rc];
     if (p < 2) {  // columns < 16 are staged for panels 2, 3 only
       const double a0 = s.D[col][j0 + rc];
-      T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, a0, T00, 0, 0, 0);
-      T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, a0, T10, 0, 0, 0);
+      T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * nr, a0, T00, 0, 0, 0);
+      T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * nr, a0, T10, 0, 0, 0);
     }
-    T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, a1, T11, 0, 0, 0);
+    T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * nr, a1, T11, 0, 0, 0);
     const int j2 = j0 + 8;  // first column of panel p + 2
     if (j2 < 16) {
       if (col >= j2 && col < j2 + 4) {
@@ -172,7 +196,7 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
   }
 }
 
-// rows [o, o+16) of the inverse of the diagonal 16x16 block at (o, o): lane c owns column o + c
+// rows [o, o+16) of the inverse of the diagonal 16x16 block of D at (o, o): lane c owns column o + c
 template <int O>
 __device__ __forceinline__ d16 f32_inverse16(Factor32Lds &s, int lane) {
   const int c = lane & 15;
@@ -186,7 +210,7 @@ __device__ __forceinline__ d16 f32_inverse16(Factor32Lds &s, int lane) {
       double v = (r == c) ? 1.0 : 0.0;
 #pragma clang loop unroll(full)
       for (int m = 0; m < r; m++) v -= s.D[O + r][O + m] * x[m];
-      const double xr = v * s.inv[O + r];
+      const double xr = v * s.rinv[O + r];  // 1 / D[r][r]
       x[r] = xr;
       // pin the row here: otherwise the compiler sinks the arithmetic below the last wait and
       // keeps every L value read so far in registers
@@ -241,6 +265,19 @@ __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim
     if (tim && lane == 0) tim[4] = (long long)__builtin_amdgcn_s_memtime();
   }
   __syncthreads();
+  if (tid < GB) {  // sq held the pivots so far
+    const double d = s.sq[tid];
+    s.sq[tid] = d * rsqrt_nr(d);
+  }
+  __syncthreads();
+}
+
+// entry (r, c) of the Cholesky factor / of its inverse from what factor32 leaves in LDS
+__device__ __forceinline__ double f32_L(const Factor32Lds &s, int r, int c) {
+  return (c <= r) ? s.D[r][c] * (s.sq[c] * s.rinv[c]) : 0.0;  // 1 / sqrt(d) = sqrt(d) / d
+}
+__device__ __forceinline__ double f32_Linv(const Factor32Lds &s, int r, int c) {
+  return (c <= r) ? s.Li[r][c] * s.sq[r] : 0.0;
 }
 
 // diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
@@ -260,8 +297,8 @@ __global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx
   double *li = linv + (size_t)(j / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
-    Lx[(size_t)(j + r) * ld + j + c] = (c <= r) ? s.D[r][c] : 0.0;
-    li[t] = (c <= r) ? s.Li[r][c] : 0.0;
+    Lx[(size_t)(j + r) * ld + j + c] = f32_L(s, r, c);
+    li[t] = f32_Linv(s, r, c);
   }
   if (tid == 0 && s.fail) status[1] = status[3];  // status[3] = this try's stamp
   if (tim && tid == 0) tim[15] = (long long)__builtin_amdgcn_s_memtime();
@@ -407,8 +444,8 @@ __device__ __forceinline__ void factor_next(Factor32Lds &s, double *Lx, int ld, 
   double *lio = linv + (size_t)(jn / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
-    Lx[(size_t)(jn + r) * ld + jn + c] = (c <= r) ? s.D[r][c] : 0.0;
-    lio[t] = (c <= r) ? s.Li[r][c] : 0.0;
+    Lx[(size_t)(jn + r) * ld + jn + c] = f32_L(s, r, c);
+    lio[t] = f32_Linv(s, r, c);
   }
   if (tid == 0 && s.fail) status[1] = status[3];
 }
