@@ -14,7 +14,10 @@
 //    of the LDS receive equal traffic, and the items of a workgroup are then dealt into rows of
 //    16 lanes whose target blocks fall into 16 different bank pairs: a ds_add_f64
 //    wave-instruction over such rows does not serialise (measured, scripts/ubench_lds.hip:
-//    8 ticks against 25 for unordered targets).  Holes are null items.
+//    8 ticks against 25 for unordered targets).  When no open row can take an item cleanly, a
+//    bank pair may be used a second time (never a third): one extra LDS pass for that row
+//    instead of a hole -- rows stay short-lived (3 open at a time), which keeps the items of a
+//    point, and with them the W rows a wave reads, together.  Remaining holes are null items.
 #include <algorithm>
 #include <cstdint>
 #include <numeric>
@@ -27,8 +30,12 @@ namespace psba {
 namespace {
 inline long long tri(long long j) { return j * (j + 1) / 2; }
 constexpr int ROW = 16;       // lanes that go through the LDS together; bank pairs of a 64-bit access
-int WINDOW = 8;               // open rows while dealing: more rows fill better but spread a point's
-                              // products over more waves (measured optimum on venice-shaped: 8)
+int DUPS = 1;                 // let a bank pair be used twice in a row once the window is full
+int WINDOW = 3;               // open rows while dealing: more rows fill better but spread a point's
+                              // products over more waves, i.e. more cache lines per load instruction
+                              // (measured on venice-shaped, scripts/k2_window_sweep.sh: strict rows
+                              // 80 / 59 / 52 / 50 / 49 us at 1 / 2 / 3 / 4 / 8; with one repeat allowed
+                              // 52 / 42 / 42 / 42 / 46 us)
 }  // namespace
 
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
@@ -36,6 +43,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   (void)nPts;
   const long long total_blocks = tri(nCams);
   if (const char *e = getenv("PSBA_SCHUR_WINDOW")) WINDOW = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = getenv("PSBA_SCHUR_DUPS")) DUPS = atoi(e);
   h->packedN = 36 * (size_t)total_blocks;
   h->nGroups = 0;
   if (nCams >= 2048) return PSBA_OK;  // boff field: track length < 2048; fall back to the atomic kernel
@@ -113,6 +121,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
 
   // ---- workgroups: about one per CU, shared between the groups in proportion to their items ----
   int nWg = 256;
+  if (const char *e = getenv("PSBA_SCHUR_NWG")) nWg = atoi(e) > 0 ? atoi(e) : nWg;
   {
     const long long cap = total_items / 512;  // small problems: no point in near-empty workgroups
     if (cap < nWg) nWg = (int)(cap < G ? G : cap);
@@ -169,7 +178,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
       const size_t base = out.items.size();
       size_t closed = 0;  // rows [0, closed) are final
-      std::vector<uint16_t> mask;
+      std::vector<uint16_t> mask, mask2;  // bank pairs used once / twice in a row
       std::vector<int> fill;
       auto row_ptr = [&](size_t r) { return out.items.data() + base + r * ROW; };
       for (size_t t = r0; t < r1; t++) {
@@ -180,9 +189,18 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
                                        ((unsigned long long)it.pos << 45);
         const uint16_t bit = (uint16_t)(1u << (it.pos % ROW));
         size_t r = closed;
-        while (r < mask.size() && (mask[r] & bit)) r++;
+        while (r < mask.size() && (fill[r] == ROW || (mask[r] & bit))) r++;
+        if (r == mask.size() && DUPS && mask.size() - closed >= (size_t)WINDOW) {
+          // no clean slot and the window is full: rather than opening a row (and closing the
+          // oldest one with holes), let a bank pair be used twice -- one extra LDS pass for
+          // that row of 16 lanes instead of idle lanes
+          r = closed;
+          while (r < mask.size() && (fill[r] == ROW || (mask2[r] & bit))) r++;
+          if (r < mask.size()) mask2[r] |= bit;
+        }
         if (r == mask.size()) {
           mask.push_back(0);
+          mask2.push_back(0);
           fill.push_back(0);
           out.items.resize(base + mask.size() * ROW, SCHUR_NULL_ITEM);
         }

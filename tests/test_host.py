@@ -84,8 +84,8 @@ def test_partition_more_ranks_than_points():
 
 def _check_plan(nC, nP, iidx, jidx):
     """Every product (a, b <= a, same point) appears exactly once, in the workgroup list of its
-    camera-row group, at its block's position; rows of 16 item slots hit 16 different bank
-    pairs; workgroup lists are equally long within a group."""
+    camera-row group, at its block's position; in a row of 16 item slots no LDS bank pair is
+    hit more than twice; workgroup lists are equally long within a group."""
     from psba_amd import capi
     plan = capi.schur_plan(nC, nP, iidx, jidx)
     assert plan["groups"] >= 1
@@ -113,7 +113,7 @@ def _check_plan(nC, nP, iidx, jidx):
         p = ((it >> np.uint64(45)) & np.uint64(0x3FF)).astype(np.int64)
         for r in range(0, len(it), 16):
             q = p[r:r + 16][live[r:r + 16]] % 16
-            assert len(set(q.tolist())) == len(q)
+            assert np.bincount(q, minlength=16).max() <= 2  # a bank pair at most twice per row
         a, i, boff, p = a[live], i[live], boff[live], p[live]
         b = a - boff
         assert (iidx[a] == i).all() and (iidx[b] == i).all() and (b >= ptr[i]).all()
