@@ -99,13 +99,26 @@ __device__ __forceinline__ double recip_cubic(double d) {
   return __builtin_fma(r0, p, r0);
 }
 
+// The pivot wave issues in order, one instruction every few cycles whether or not it is on the
+// dependent chain, so its instruction count is kept down as well: the 16 scalars of the row
+// update come as broadcast LDS reads of the panel just published (not 32 readlanes), the
+// columns are published unmasked (what lands above the diagonal only ever reaches dead entries:
+// the consumers read the lower triangle, and as MFMA operands those values only touch rows /
+// columns that are already final), and 1/d, d are stored once per panel.
 __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long long *tim = nullptr) {
   const int row = lane & 31;
   bool bad = false;
-  d4 a, ap = {0, 0, 0, 0}, tp = {0, 0, 0, 0};  // this panel's columns; the previous one's, and those / d
+  d4 a, tp = {0, 0, 0, 0};  // this panel's columns; the previous panel's divided by their pivots
 #pragma clang loop unroll(full)
   for (int q = 0; q < 8; q++) {
     const int j0 = 4 * q;
+    double sc[4][4];  // the previous panel's entries in this panel's four pivot rows
+    if (q > 0) {
+#pragma unroll
+      for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) sc[k2][k] = s.D[j0 + k2][j0 - 4 + k];
+    }
     if (q < 2) {
 #pragma unroll
       for (int k = 0; k < 4; k++) a[k] = s.D[row][j0 + k];
@@ -123,19 +136,17 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
 #pragma clang loop unroll(full)
       for (int k2 = 0; k2 < 4; k2++)
 #pragma clang loop unroll(full)
-        for (int k = 0; k < 4; k++) a[k2] -= tp[k] * readlane_f64g(ap[k], j0 + k2);
+        for (int k = 0; k < 4; k++) a[k2] -= tp[k] * sc[k2][k];
     }
-    d4 t;
+    d4 t, rr, dd;
     double d = readlane_f64g(a[0], j0);
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; k++) {
-      bad |= !(d > 0.0) || !(d < 1.7e308);
+      bad |= !(d > 0.0);  // also NaN; an infinite pivot ends in a non-finite solution, caught there
       const double r = recip_cubic(d);
       t[k] = a[k] * r;
-      if (lane == 0) {
-        s.rinv[j0 + k] = r;
-        s.sq[j0 + k] = d;  // the square root is taken at the end, off the chain
-      }
+      rr[k] = r;
+      dd[k] = d;  // the square root is taken at the end, off the chain
       if (k < 3) {
         // the next pivot, in its own lane: no broadcast between two pivots but the pivot itself
         d = readlane_f64g(__builtin_fma(-t[k], a[k], a[k + 1]), j0 + k + 1);
@@ -144,12 +155,16 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
       }
     }
     if (q == 0) f32_wait(&s.flag[2], 1);  // the tile wave reads the original block first
-    if (lane < 32) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) s.D[row][j0 + k] = (row >= j0 + k) ? a[k] : 0.0;
+    for (int k = 0; k < 4; k++) s.D[row][j0 + k] = a[k];  // lanes 32..63 repeat lanes 0..31
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s.rinv[j0 + k] = rr[k];
+        s.sq[j0 + k] = dd[k];
+      }
     }
     f32_post(&s.flag[0], q + 1, lane);
-    ap = a;
     tp = t;
     if (tim && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
   }
