@@ -82,8 +82,9 @@ struct Factor32Lds {
 };
 
 __device__ __forceinline__ void f32_wait(int *flag, int v) {
-  while (__hip_atomic_load((lds_int *)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v)
-    __builtin_amdgcn_s_sleep(1);
+  // a tight poll: each of the four waves has a SIMD to itself, and the LDS round trip paces it
+  while (__hip_atomic_load((lds_int *)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void f32_post(int *flag, int v, int lane) {
