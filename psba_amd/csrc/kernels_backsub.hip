@@ -10,6 +10,8 @@
 // Per tile of whole points: thread per observation forms W_ij^T dpa_j; thread per point
 // finishes e_b,i, applies V*_i^-1, writes dpb_i and the proposed point; thread per
 // observation then evaluates the residual at the proposal.
+#include <cstdlib>
+
 #include "camera_model.h"
 #include "psba_internal.h"
 
@@ -17,15 +19,17 @@ namespace psba {
 
 struct BackArgs {
   const double *W, *PV, *camconst, *cams, *pts, *impts, *ga;
-  const int *iidx, *jidx, *ptr, *tile_pt;
+  const int *iidx, *jidx, *ptr;
+  const int4 *tile_desc;
   double *dp;          // [nA] dpa (in) | [nB] dpb (out)
   double *newcams, *newpts;
-  double *scal;        // SC_DP_L2, SC_GAIN_DEN, SC_NEW_COST, SC_NEWP_L2 accumulate here
+  double *scal;        // the four sums accumulate in scal[SC_PART ...]
   double *dbg_eb;
   const int *status;   // [0] singular-V stamp, [1] not-SPD stamp, [3] this try's stamp
   double mu;
   int nC, nA, nTiles;
   int cam_terms;       // 1 on the rank that owns the camera terms of the scalar sums
+  int mode;            // development ablation (PSBA_BACK_MODE): 1 no residual pass, 2 no W^T dpa pass
 };
 
 template <bool DUMP>
@@ -39,11 +43,11 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
   // camera part (once): proposal cams + dpa and the camera terms of the scalar sums.
   // g_a here is this rank's partial; the sum over ranks of dpa.g_a is the full term.
   if (blockIdx.x == 0) {
-    // the try's status as summable flags next to the four sums (slots SC_DP_L2+4, +5), so that
+    // the try's status as summable flags right behind the partial sums, so that
     // one all-reduce (sum) over ranks covers scalars and status
     if (tid == 0) {
-      p.scal[SC_DP_L2 + 4] = (p.status[0] == p.status[3]) ? 1.0 : 0.0;
-      p.scal[SC_DP_L2 + 5] = (p.status[1] == p.status[3]) ? 1.0 : 0.0;
+      p.scal[SC_STATUS_V] = (p.status[0] == p.status[3]) ? 1.0 : 0.0;
+      p.scal[SC_STATUS_SPD] = (p.status[1] == p.status[3]) ? 1.0 : 0.0;
     }
     for (int t = tid; t < p.nA; t += TILE_OBS) {
       const double d = p.dp[t], c = p.cams[t] + d;
@@ -57,15 +61,27 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     }
   }
 
-  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
-    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
-    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+  // the dependent index loads of a tile (descriptor -> observation indices -> point CSR) are
+  // issued one tile ahead
+  int tile = blockIdx.x;
+  int4 dsc = tile < p.nTiles ? p.tile_desc[tile] : make_int4(0, 0, 0, 0);
+  int i = 0, j = 0;
+  if (dsc.z + tid < dsc.w) {
+    i = p.iidx[dsc.z + tid];
+    j = p.jidx[dsc.z + tid];
+  }
+  for (; tile < p.nTiles; tile += gridDim.x) {
+    const int p0 = dsc.x, p1 = dsc.y, o0 = dsc.z, o1 = dsc.w;
     const int a = o0 + tid;
-    int i = 0, j = 0;
+    const int tn = tile + gridDim.x;
+    const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
+    int pb0 = 0, pb1 = 0;  // CSR bounds of this thread's point
+    if (p0 + tid < p1) {
+      pb0 = p.ptr[p0 + tid] - o0;
+      pb1 = p.ptr[p0 + tid + 1] - o0;
+    }
     __syncthreads();
-    if (a < o1) {
-      i = p.iidx[a];
-      j = p.jidx[a];
+    if (a < o1 && p.mode != 2) {
       const double *w = p.W + 18 * (size_t)a;
       const double *da = p.dp + 6 * j;
       double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -84,7 +100,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     if (p0 + tid < p1) {
       const int ip = p0 + tid;
       const double *pv = p.PV + 9 * (size_t)ip;
-      const int b0 = p.ptr[ip] - o0, b1 = p.ptr[ip + 1] - o0;
+      const int b0 = pb0, b1 = pb1;
       const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
       double e0 = 0.0, e1 = 0.0, e2 = 0.0;
       for (int b = b0; b < b1; b++) {
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
       s_np += n0 * n0 + n1 * n1 + n2 * n2;
     }
     __syncthreads();
-    if (a < o1) {
+    if (a < o1 && p.mode != 1) {
       double cc[9], cam[6], e0, e1;
 #pragma unroll
       for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
@@ -137,6 +153,12 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
       const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
       residual_obs(cc, cc + 5, cam, sNP[i - p0], m.x, m.y, e0, e1);
       s_cost += e0 * e0 + e1 * e1;
+    }
+    dsc = dn;
+    i = j = 0;
+    if (dsc.z + tid < dsc.w) {
+      i = p.iidx[dsc.z + tid];
+      j = p.jidx[dsc.z + tid];
     }
   }
   // workgroup reduction of the four sums, one atomic each
@@ -150,10 +172,10 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
   }
   __syncthreads();
   // one wave-instruction with four lanes: same-address atomics serialise at ~13 ns per
-  // request, so the number of requests (workgroups), not lanes, is what costs
+  // request, so the requests are spread over SC_NPART partial sets (summed on the host)
   if (tid < 4) {
     const double v = sRed[tid][0] + sRed[tid][1] + sRed[tid][2] + sRed[tid][3];
-    atomicAdd(&p.scal[SC_DP_L2 + tid], v);
+    atomicAdd(&p.scal[SC_PART + 4 * (blockIdx.x % SC_NPART) + tid], v);
   }
 }
 
@@ -170,7 +192,7 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   a.iidx = h->iidx;
   a.jidx = h->jidx;
   a.ptr = h->ptr;
-  a.tile_pt = h->tile_pt;
+  a.tile_desc = h->tile_desc;
   a.dp = h->dp;
   a.newcams = h->cams[1 - h->cur];
   a.newpts = h->pts[1 - h->cur];
@@ -182,10 +204,16 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   a.nA = d.nA;
   a.nTiles = d.nTiles;
   a.cam_terms = h->rank == 0 ? 1 : 0;
+  {
+    const char *m = getenv("PSBA_BACK_MODE");
+    a.mode = m ? atoi(m) : 0;
+  }
   // the fused path's accumulators are zeroed by this try's k_schur_reduce; the sba_func.h mirror
   // may run K3 more than once per assembly, so it zeroes them here
-  if (dump) PSBA_HIP(h, hipMemsetAsync(h->scal + SC_DP_L2, 0, 4 * sizeof(double), h->stream));
-  int grid = d.nTiles < 512 ? d.nTiles : 512;  // persistent workgroups: few atomic requests
+  if (dump) PSBA_HIP(h, hipMemsetAsync(h->scal + SC_PART, 0, 4 * SC_NPART * sizeof(double), h->stream));
+  // persistent workgroups, enough of them per CU to hide the three dependent load phases of a tile
+  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  if (const char *e = getenv("PSBA_BACK_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;
   {
     ProfScope ps(h, PSBA_K_BACKSUB);
     if (dump)

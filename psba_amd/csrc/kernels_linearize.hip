@@ -11,6 +11,8 @@
 // reference's summation order); the 27 per-camera sums (sym U_j, g_a,j) are accumulated in
 // LDS per workgroup and written once per workgroup as a partial slab that k_cam_reduce
 // sums in slab order.  Nothing per-observation except W is written to HBM.
+#include <cstdlib>
+
 #include "camera_model.h"
 #include "psba_internal.h"
 
@@ -18,11 +20,13 @@ namespace psba {
 
 struct LinArgs {
   const double *camconst, *cams, *pts, *impts;
-  const int *iidx, *jidx, *ptr, *tile_pt;
+  const int *iidx, *jidx, *ptr;
+  const int4 *tile_desc;
   double *W, *PV, *campart;
   double *dbg_ex, *dbg_JA, *dbg_JB;
   double coeff, coeff_g;
   int nC, nTiles;
+  int mode;  // development ablation (PSBA_LIN_MODE): 1 no camera atomics, 2 no W store, 3 no per-point sums
 };
 
 template <bool DUMP>
@@ -35,12 +39,30 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   for (int t = tid; t < nAcc; t += TILE_OBS) sAcc[t] = 0.0;
   __syncthreads();
 
-  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
-    const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
-    const int o0 = p.ptr[p0], o1 = p.ptr[p1];
+  // a workgroup has only a few tiles and few neighbours on its CU (LDS), so the dependent index
+  // loads of a tile (descriptor -> observation indices -> point CSR) are issued one tile ahead
+  int tile = blockIdx.x;
+  int4 dsc = tile < p.nTiles ? p.tile_desc[tile] : make_int4(0, 0, 0, 0);
+  int i = 0, j = 0;
+  if (dsc.z + tid < dsc.w) {
+    i = p.iidx[dsc.z + tid];
+    j = p.jidx[dsc.z + tid];
+  }
+  for (; tile < p.nTiles; tile += gridDim.x) {
+    const int p0 = dsc.x, p1 = dsc.y, o0 = dsc.z, o1 = dsc.w;
     const int a = o0 + tid;
+    const int tn = tile + gridDim.x;
+    const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
+    // CSR bounds of the (point, component) tasks of this thread (see below)
+    constexpr int NTASK = (9 * TILE_PTS + TILE_OBS - 1) / TILE_OBS;  // rounds of (point, component) tasks
+    int pb[NTASK][2];
+#pragma unroll
+    for (int u = 0; u < NTASK; u++) {
+      const int ip = (tid + u * TILE_OBS) / 9;
+      pb[u][0] = ip < p1 - p0 ? p.ptr[p0 + ip] - o0 : 0;
+      pb[u][1] = ip < p1 - p0 ? p.ptr[p0 + ip + 1] - o0 : 0;
+    }
     if (a < o1) {
-      const int i = p.iidx[a], j = p.jidx[a];
       double cc[9], cam[6], M[3], e[2], A[12], B[6];
 #pragma unroll
       for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
@@ -73,42 +95,55 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
       // camera sums: upper triangle of A^T A, then A^T e
       double *acc = sAcc + CAM_ACC * j;
       int k = 0;
+      if (p.mode != 1) {
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
         for (int c = r; c < 6; c++) atomicAdd(&acc[k++], A[r] * A[c] + A[6 + r] * A[6 + c]);
 #pragma unroll
       for (int r = 0; r < 6; r++) atomicAdd(&acc[21 + r], A[r] * e[0] + A[6 + r] * e[1]);
+      }
     }
     __syncthreads();
-    {
+    if (p.mode != 2) {
       double *dst = p.W + 18 * (size_t)o0;
       const int n = 18 * (o1 - o0);
       for (int t = tid; t < n; t += TILE_OBS) dst[t] = sW[19 * (t / 18) + t % 18];
     }
-    // one thread per point: V_i (sym6) and g_b,i in camera-ascending order
-    const int i = p0 + tid;
-    if (i < p1) {
-      const int b0 = p.ptr[i] - o0, b1 = p.ptr[i + 1] - o0;
-      double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    // V_i (sym6) and g_b,i: one thread per (point, component), each summing over the point's
+    // observations in camera-ascending order (the reference's order, so V is reproducible bit
+    // for bit); nine lanes per point instead of one keeps the lanes busy and the stores coalesced
+#pragma unroll
+    for (int u = 0; u < NTASK; u++) {
+      const int t = tid + u * TILE_OBS;
+      if (t >= 9 * (p1 - p0) || p.mode == 3) continue;
+      const int comp = t % 9;
+      const int b0 = pb[u][0], b1 = pb[u][1];
+      // component -> the two products it sums: B[r] * B[c] + B[3+r] * B[3+c]   (V, r <= c)
+      //                                    or  B[r] * e0   + B[3+r] * e1      (g_b)
+      int r, c1, c2;
+      if (comp < 6) {
+        r = comp < 3 ? 0 : (comp < 5 ? 1 : 2);
+        const int c = comp < 3 ? comp : (comp < 5 ? comp - 2 : 2);
+        c1 = c;
+        c2 = 3 + c;
+      } else {
+        r = comp - 6;
+        c1 = 6;
+        c2 = 7;
+      }
+      double acc = 0.0;
       for (int b = b0; b < b1; b++) {
         const double *B = sBE[b];
-        const double e0 = B[6], e1 = B[7];
-        v[0] += B[0] * B[0] + B[3] * B[3];
-        v[1] += B[0] * B[1] + B[3] * B[4];
-        v[2] += B[0] * B[2] + B[3] * B[5];
-        v[3] += B[1] * B[1] + B[4] * B[4];
-        v[4] += B[1] * B[2] + B[4] * B[5];
-        v[5] += B[2] * B[2] + B[5] * B[5];
-        g[0] += B[0] * e0 + B[3] * e1;
-        g[1] += B[1] * e0 + B[4] * e1;
-        g[2] += B[2] * e0 + B[5] * e1;
+        acc += B[r] * B[c1] + B[3 + r] * B[c2];
       }
-      double *o = p.PV + 9 * (size_t)i;
-#pragma unroll
-      for (int k = 0; k < 6; k++) o[k] = p.coeff * v[k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) o[6 + k] = p.coeff_g * g[k];
+      p.PV[9 * (size_t)p0 + t] = (comp < 6 ? p.coeff : p.coeff_g) * acc;
+    }
+    dsc = dn;
+    i = j = 0;
+    if (dsc.z + tid < dsc.w) {
+      i = p.iidx[dsc.z + tid];
+      j = p.jidx[dsc.z + tid];
     }
     __syncthreads();
   }
@@ -221,7 +256,7 @@ int launch_linearize(psba_ctx *h, bool dump) {
   a.iidx = h->iidx;
   a.jidx = h->jidx;
   a.ptr = h->ptr;
-  a.tile_pt = h->tile_pt;
+  a.tile_desc = h->tile_desc;
   a.W = h->W;
   a.PV = h->PV;
   a.campart = h->campart;
@@ -232,6 +267,10 @@ int launch_linearize(psba_ctx *h, bool dump) {
   a.coeff_g = h->coeff_g;
   a.nC = d.nC;
   a.nTiles = d.nTiles;
+  {
+    const char *m = getenv("PSBA_LIN_MODE");
+    a.mode = m ? atoi(m) : 0;
+  }
   const size_t lds = sizeof(double) * CAM_ACC * (size_t)d.nC;
   {
     ProfScope ps(h, PSBA_K_LINEARIZE);

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   __shared__ double sAcc[4][64];
   // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
   // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
-  if (blockIdx.x == 0 && threadIdx.x < 4) p.scal[SC_DP_L2 + threadIdx.x] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x == 4) p.status[3] = p.try_id;
+  if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) p.scal[SC_PART + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 64) p.status[3] = p.try_id;
   write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                 (size_t)gridDim.x * blockDim.x);
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, c
                                                         const double *ga, double mu_add, int nA,
                                                         int n32, double pad_one, double *scal,
                                                         int *status, int try_id) {
-  if (blockIdx.x == 0 && threadIdx.x < 4) scal[SC_DP_L2 + threadIdx.x] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x == 4) status[3] = try_id;
+  if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) scal[SC_PART + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 64) status[3] = try_id;
   const size_t n2 = (size_t)nA * nA;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t gsize = (size_t)gridDim.x * blockDim.x;

@@ -97,6 +97,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->jidx);
   dev_free(h->ptr);
   dev_free(h->tile_pt);
+  dev_free(h->tile_desc);
   dev_free(h->W);
   dev_free(h->PV);
   dev_free(h->U);
@@ -234,6 +235,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
                 "not supported yet", nCams, (size_t)CAM_ACC * nCams * sizeof(double));
   h->d = d;
   h->nPart = d.nTiles < 512 ? d.nTiles : 512;
+  if (const char *e = getenv("PSBA_LIN_GRID")) h->nPart = atoi(e) > 0 && atoi(e) < d.nTiles ? atoi(e) : d.nTiles;
   h->cur = 0;
 
   std::vector<double> cc((size_t)nCams * 9);
@@ -251,6 +253,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->jidx, (size_t)d.nO));
   TRY(dev_alloc(h, &h->ptr, (size_t)d.nP + 1));
   TRY(dev_alloc(h, &h->tile_pt, tile_pt.size()));
+  TRY(dev_alloc(h, &h->tile_desc, (size_t)d.nTiles));
   TRY(dev_alloc(h, &h->W, (size_t)18 * d.nO));
   TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
   TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
@@ -296,6 +299,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, H2D(h->jidx, jidx, sizeof(int) * (size_t)d.nO));
   PSBA_HIP(h, H2D(h->ptr, ptr.data(), sizeof(int) * ptr.size()));
   PSBA_HIP(h, H2D(h->tile_pt, tile_pt.data(), sizeof(int) * tile_pt.size()));
+  std::vector<int4> tile_desc((size_t)d.nTiles);
+  for (int t = 0; t < d.nTiles; t++)
+    tile_desc[t] = make_int4(tile_pt[t], tile_pt[t + 1], ptr[tile_pt[t]], ptr[tile_pt[t + 1]]);
+  PSBA_HIP(h, hipMemcpy(h->tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice));
   PSBA_HIP(h, hipMemsetAsync(h->dp, 0, sizeof(double) * d.nT, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
   h->uploaded = true;
@@ -426,12 +433,18 @@ int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
   NEED(h, h->solved, "psba_schur_solve first");
   TRY(launch_backsub(h, mu, false));
   if (h->comm)  // four sums + two status flags in one collective
-    RCCL(h, ncclAllReduce(h->scal + SC_DP_L2, h->scal + SC_DP_L2, 6, ncclDouble, ncclSum, h->comm,
-                          h->stream));
+    RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum,
+                          h->comm, h->stream));
   TRY(fetch_scalars(h));
+  // the four sums arrive as SC_NPART partial sets: add them up in a fixed order
+  for (int q = 0; q < 4; q++) {
+    double v = 0.0;
+    for (int s = 0; s < SC_NPART; s++) v += h->h_scal[SC_PART + 4 * s + q];
+    h->h_scal[SC_DP_L2 + q] = v;
+  }
   // K3 publishes the status as flags (summed over ranks): > 0 <=> flagged on some rank
-  const int st0 = h->h_scal[SC_DP_L2 + 4] > 0.0 ? h->try_id : 0;
-  const int st1 = h->h_scal[SC_DP_L2 + 5] > 0.0 ? h->try_id : 0;
+  const int st0 = h->h_scal[SC_STATUS_V] > 0.0 ? h->try_id : 0;
+  const int st1 = h->h_scal[SC_STATUS_SPD] > 0.0 ? h->try_id : 0;
   h->backsubbed = true;
   h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   if (out) {

@@ -16,7 +16,8 @@ constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= thread
 constexpr int TILE_PTS = 128;   // points per tile (bounds the per-point LDS rows)
 constexpr int MAX_GROUPS = 32;  // camera-row groups of the LDS-resident S partition (K2)
 constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
-constexpr int NSCAL = 16;       // device scalar block (doubles)
+constexpr int NSCAL = 96;       // device scalar block (doubles)
+constexpr int SC_NPART = 16;    // K3's four sums arrive in 16 partial sets (same-address atomics serialise)
 
 // slots of the device scalar block
 enum {
@@ -25,9 +26,11 @@ enum {
   SC_GAIN_DEN = 2,
   SC_NEW_COST = 3,
   SC_NEWP_L2 = 4,
-  SC_STATUS_V = 5,   // K3: 1.0 when some V_i was singular in this try (summable over ranks)
-  SC_STATUS_SPD = 6, // K3: 1.0 when the Cholesky of this try failed
   SC_MAXDIAG = 7,
+  // [8..9] alias the status words (ints)
+  SC_PART = 16,      // K3: [SC_NPART][4] partial (dp_l2, gain_den, new_cost, newp_l2), summed on the host
+  SC_STATUS_V = 80,  // K3: 1.0 when some V_i was singular in this try (summable over ranks)
+  SC_STATUS_SPD = 81,  // K3: 1.0 when the Cholesky of this try failed
 };
 
 struct Dims {
@@ -74,6 +77,7 @@ struct psba_ctx {
   int *jidx = nullptr;          // [nO] camera of each observation   (jidx_buffer)
   int *ptr = nullptr;           // [nP+1] point CSR over observations (replaces blkIdx_buffer)
   int *tile_pt = nullptr;       // [nTiles+1] first point of each tile
+  int4 *tile_desc = nullptr;    // [nTiles] (first point, end point, first observation, end observation): one load instead of a chain
   double *W = nullptr;          // [nO][18] W_ij = coeff A^T B        (W_buffer)
   double *PV = nullptr;         // [nP][9]  V_i sym6 | g_b,i          (V_buffer + g_buffer tail)
   double *U = nullptr;          // [nC][36]                           (U_buffer)
