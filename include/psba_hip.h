@@ -122,6 +122,16 @@ typedef struct {
  * loop needs, in one kernel (PSBA/sba_func.h:124-137, PSBA/levmar.cpp:151-195).
  * Synchronises and fills *out (all-reduced over ranks). */
 int psba_backsub(psba_handle h, double mu, psba_try_scalars *out);
+/* The same in two halves, so that the host's decision (PSBA/levmar.cpp:169-223) no longer idles
+ * the GPU: psba_backsub_async queues the kernel and the copy of its scalars and returns;
+ * psba_linearize_ahead then queues psba_linearize's work for the PROPOSED parameters into a
+ * second set of linearization buffers (the current linearization stays valid); psba_backsub_wait
+ * waits for the scalars only.  If the step is accepted, psba_accept makes the proposed
+ * parameters AND the linearization computed ahead current, and the next psba_linearize (same
+ * coefficients) has nothing left to do; if it is rejected the work done ahead is dropped. */
+int psba_backsub_async(psba_handle h, double mu);
+int psba_linearize_ahead(psba_handle h);
+int psba_backsub_wait(psba_handle h, psba_try_scalars *out);
 /* update_p (PSBA/sba_func.h:138): the proposed parameters become current (pointer swap) */
 int psba_accept(psba_handle h);
 

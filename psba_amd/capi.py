@@ -64,6 +64,9 @@ SIGNATURES = [
     ("psba_schur_reduce", C.c_int, [_h]),
     ("psba_schur_solve", C.c_int, [_h]),
     ("psba_backsub", C.c_int, [_h, C.c_double, C.POINTER(TryScalars)]),
+    ("psba_backsub_async", C.c_int, [_h, C.c_double]),
+    ("psba_linearize_ahead", C.c_int, [_h]),
+    ("psba_backsub_wait", C.c_int, [_h, C.POINTER(TryScalars)]),
     ("psba_accept", C.c_int, [_h]),
     ("psba_compute_exQT", C.c_int, [_h, C.c_int, _dp]),
     ("psba_compute_jacobiQT", C.c_int, [_h, _dp, _dp]),
@@ -266,6 +269,17 @@ class Psba:
     def backsub(self, mu):
         s = TryScalars()
         self._ck(lib.psba_backsub(self._h, mu, C.byref(s)))
+        return s
+
+    def backsub_async(self, mu):
+        self._ck(lib.psba_backsub_async(self._h, mu))
+
+    def linearize_ahead(self):
+        self._ck(lib.psba_linearize_ahead(self._h))
+
+    def backsub_wait(self):
+        s = TryScalars()
+        self._ck(lib.psba_backsub_wait(self._h, C.byref(s)))
         return s
 
     def accept(self):

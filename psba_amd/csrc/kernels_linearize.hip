@@ -246,19 +246,21 @@ __global__ __launch_bounds__(256) void k_max_diag(const double *U, const double 
   }
 }
 
-int launch_linearize(psba_ctx *h, bool dump) {
+int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
   const Dims &d = h->d;
   LinArgs a;
   a.camconst = h->camconst;
-  a.cams = h->cams[h->cur];
-  a.pts = h->pts[h->cur];
+  // ahead: the proposed parameters, into the alternate set of outputs
+  const int set = ahead ? 1 - h->cur : h->cur;
+  a.cams = h->cams[set];
+  a.pts = h->pts[set];
   a.impts = h->impts;
   a.iidx = h->iidx;
   a.jidx = h->jidx;
   a.ptr = h->ptr;
   a.tile_desc = h->tile_desc;
-  a.W = h->W;
-  a.PV = h->PV;
+  a.W = ahead ? h->W_alt : h->W;
+  a.PV = ahead ? h->PV_alt : h->PV;
   a.campart = h->campart;
   a.dbg_ex = h->dbg_ex;
   a.dbg_JA = h->dbg_JA;
@@ -279,7 +281,7 @@ int launch_linearize(psba_ctx *h, bool dump) {
     else
       hipLaunchKernelGGL(k_linearize<false>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
     hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, h->nPart,
-                       d.nC, h->coeff, h->coeff_g, h->U, h->ga);
+                       d.nC, h->coeff, h->coeff_g, ahead ? h->U_alt : h->U, ahead ? h->ga_alt : h->ga);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

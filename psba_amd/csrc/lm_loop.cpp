@@ -60,7 +60,11 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
       LM_TRY(psba_schur_assemble(h, mu));  // :126-131
       LM_TRY(psba_schur_reduce(h));
       LM_TRY(psba_schur_solve(h));         // :134-140
-      LM_TRY(psba_backsub(h, mu, &sc));    // :151-157,185-193
+      // :151-157,185-193 -- and, while the host looks at the scalars, the next iteration's
+      // linearization at the proposed parameters (dropped if the step is rejected)
+      LM_TRY(psba_backsub_async(h, mu));
+      LM_TRY(psba_linearize_ahead(h));
+      LM_TRY(psba_backsub_wait(h, &sc));
       if (!(sc.status & PSBA_NOT_SPD)) {
         dp_L2 = sc.dp_l2;
         if (dp_L2 < p_L2 * STOP * STOP) {  // :169-173

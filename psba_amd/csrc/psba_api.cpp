@@ -99,6 +99,10 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->tile_pt);
   dev_free(h->tile_desc);
   dev_free(h->W);
+  dev_free(h->W_alt);
+  dev_free(h->PV_alt);
+  dev_free(h->U_alt);
+  dev_free(h->ga_alt);
   dev_free(h->PV);
   dev_free(h->U);
   dev_free(h->ga);
@@ -142,7 +146,7 @@ int psba_create(int device, psba_handle *out) {
       (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void **)&h->scal, sizeof(double) * NSCAL)) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * NSCAL)) != hipSuccess ||
-      false) {
+      (e = hipEventCreateWithFlags(&h->scal_event, hipEventDisableTiming)) != hipSuccess) {
     int rc = fail(nullptr, PSBA_E_HIP, "psba_create: %s", hipGetErrorString(e));
     delete h;
     return rc;
@@ -163,6 +167,7 @@ int psba_destroy(psba_handle h) {
   free_problem_buffers(h);
   dev_free(h->scal);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->scal_event) (void)hipEventDestroy(h->scal_event);
   for (auto &s : h->spans) {
     (void)hipEventDestroy(s.a);
     (void)hipEventDestroy(s.b);
@@ -255,9 +260,14 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->tile_pt, tile_pt.size()));
   TRY(dev_alloc(h, &h->tile_desc, (size_t)d.nTiles));
   TRY(dev_alloc(h, &h->W, (size_t)18 * d.nO));
+  TRY(dev_alloc(h, &h->W_alt, (size_t)18 * d.nO));
   TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
+  TRY(dev_alloc(h, &h->PV_alt, (size_t)9 * d.nP));
   TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
+  TRY(dev_alloc(h, &h->U_alt, (size_t)36 * d.nC));
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
+  TRY(dev_alloc(h, &h->ga_alt, (size_t)d.nA));
+  h->ahead = h->lin_is_ahead = false;
   TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
   h->n32 = (d.nA + 31) / 32 * 32;
   // rows [0, n32 + 16) are the reduce buffer proper; n32 more rows below it are the working
@@ -318,6 +328,7 @@ int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D) {
                              hipMemcpyHostToDevice, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));
   h->linearized = h->assembled = h->solved = h->backsubbed = false;
+  h->ahead = h->lin_is_ahead = h->backsub_pending = false;
   return PSBA_OK;
 }
 
@@ -359,9 +370,14 @@ int psba_residual(psba_handle h, int which, double *cost) {
 int psba_linearize(psba_handle h, double coeff, double coeff_g) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  h->coeff = coeff;
-  h->coeff_g = coeff_g;
-  TRY(launch_linearize(h, false));
+  // nothing to do when psba_linearize_ahead already produced exactly this linearization
+  if (!(h->lin_is_ahead && coeff == h->coeff && coeff_g == h->coeff_g)) {
+    h->coeff = coeff;
+    h->coeff_g = coeff_g;
+    TRY(launch_linearize(h, false));
+  }
+  h->lin_is_ahead = false;
+  h->ahead = false;
   h->linearized = true;
   h->assembled = h->solved = h->backsubbed = false;
   return PSBA_OK;
@@ -428,14 +444,35 @@ int psba_schur_solve(psba_handle h) {
   return PSBA_OK;
 }
 
-int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
+int psba_backsub_async(psba_handle h, double mu) {
   CHECK_H(h);
   NEED(h, h->solved, "psba_schur_solve first");
   TRY(launch_backsub(h, mu, false));
-  if (h->comm)  // four sums + two status flags in one collective
+  if (h->comm)  // four sums (as partial sets) + two status flags in one collective
     RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum,
                           h->comm, h->stream));
-  TRY(fetch_scalars(h));
+  PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost,
+                             h->stream));
+  PSBA_HIP(h, hipEventRecord(h->scal_event, h->stream));
+  h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
+  h->backsub_pending = true;
+  h->ahead = false;
+  return PSBA_OK;
+}
+
+int psba_linearize_ahead(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->backsub_pending || h->backsubbed, "psba_backsub_async / psba_backsub first");
+  TRY(launch_linearize(h, false, true));
+  h->ahead = true;
+  return PSBA_OK;
+}
+
+int psba_backsub_wait(psba_handle h, psba_try_scalars *out) {
+  CHECK_H(h);
+  NEED(h, h->backsub_pending, "psba_backsub_async first");
+  PSBA_HIP(h, hipEventSynchronize(h->scal_event));
+  h->backsub_pending = false;
   // the four sums arrive as SC_NPART partial sets: add them up in a fixed order
   for (int q = 0; q < 4; q++) {
     double v = 0.0;
@@ -446,7 +483,6 @@ int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
   const int st0 = h->h_scal[SC_STATUS_V] > 0.0 ? h->try_id : 0;
   const int st1 = h->h_scal[SC_STATUS_SPD] > 0.0 ? h->try_id : 0;
   h->backsubbed = true;
-  h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   if (out) {
     out->status = (st1 == h->try_id ? PSBA_NOT_SPD : 0) | (st0 == h->try_id ? PSBA_SINGULAR_V : 0);
     out->dp_l2 = h->h_scal[SC_DP_L2];
@@ -457,11 +493,24 @@ int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
   return PSBA_OK;
 }
 
+int psba_backsub(psba_handle h, double mu, psba_try_scalars *out) {
+  TRY(psba_backsub_async(h, mu));
+  return psba_backsub_wait(h, out);
+}
+
 int psba_accept(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->backsubbed, "psba_backsub first");
   h->cur = 1 - h->cur;
   h->linearized = h->assembled = h->solved = h->backsubbed = false;
+  if (h->ahead) {  // the linearization at the (now current) proposed parameters exists already
+    std::swap(h->W, h->W_alt);
+    std::swap(h->PV, h->PV_alt);
+    std::swap(h->U, h->U_alt);
+    std::swap(h->ga, h->ga_alt);
+    h->lin_is_ahead = true;
+  }
+  h->ahead = false;
   return PSBA_OK;
 }
 

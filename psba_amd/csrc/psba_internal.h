@@ -82,6 +82,12 @@ struct psba_ctx {
   double *PV = nullptr;         // [nP][9]  V_i sym6 | g_b,i          (V_buffer + g_buffer tail)
   double *U = nullptr;          // [nC][36]                           (U_buffer)
   double *ga = nullptr;         // [nA]                               (g_buffer head)
+  // second set of linearization outputs, written by psba_linearize_ahead for the proposed
+  // parameters while the host decides about the step; psba_accept swaps the sets
+  double *W_alt = nullptr, *PV_alt = nullptr, *U_alt = nullptr, *ga_alt = nullptr;
+  bool ahead = false;           // the alternate set holds the linearization at the proposed parameters
+  bool lin_is_ahead = false;    // the current set was computed ahead: the next psba_linearize is a no-op
+  hipEvent_t scal_event = nullptr;  // recorded behind the scalar copy of psba_backsub_async
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
   int nPart = 0;
   // padded reduce buffer Lw[(n32+16)][n32], n32 = nA rounded up to 32: rows < nA = S (row stride
@@ -121,6 +127,7 @@ struct psba_ctx {
 
   // ---- state ----
   bool uploaded = false, linearized = false, assembled = false, solved = false, backsubbed = false;
+  bool backsub_pending = false;  // psba_backsub_async issued, psba_backsub_wait not yet
   int cur = 0;                  // index of the current parameter set in cams[]/pts[]
   double coeff = 1.0, coeff_g = 1.0, mu = 0.0;
   bool mu_applied = false;      // update_UV called (fine-grained mirror only)
@@ -155,7 +162,7 @@ struct ProfScope {
 
 // ---- kernel launchers (one per .hip file) ----
 // kernels_linearize.hip
-int launch_linearize(psba_ctx *h, bool dump);
+int launch_linearize(psba_ctx *h, bool dump, bool ahead = false);
 int launch_residual(psba_ctx *h, int which, double *ex_out_dev);
 int launch_max_diag(psba_ctx *h);
 // kernels_schur.hip

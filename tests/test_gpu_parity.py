@@ -408,3 +408,46 @@ def test_unfused_panel_chain(problems, monkeypatch):
     assert rc == 0
     close(dpa, dp[: o.nA], 1e-9, "dpa")
     h.close()
+
+
+def test_linearize_ahead_equals_plain_verbs(problems):
+    """psba_backsub_async + psba_linearize_ahead + psba_backsub_wait (the host decides while the
+    GPU already linearizes at the proposed parameters) must give the same iterates as the plain
+    verb sequence, through accepted and rejected steps alike."""
+    import psba_amd
+    prob = problems["54cams"]
+
+    def run(ahead):
+        h = psba_amd.Psba(0)
+        h.upload_problem(prob)
+        cost = h.residual()
+        h.linearize(1.0, 1.0)
+        mu = 1e-3 * h.max_diag()
+        costs, nu = [], 2
+        for it in range(6):
+            h.linearize(1.0, 1.0)
+            # the second try of iteration 2 is forced to fail (huge negative damping is not SPD)
+            for attempt in range(3):
+                m = -1e30 if (it == 2 and attempt == 0) else mu
+                h.schur_assemble(m); h.schur_reduce(); h.schur_solve()
+                if ahead:
+                    h.backsub_async(m); h.linearize_ahead(); sc = h.backsub_wait()
+                else:
+                    sc = h.backsub(m)
+                if not (sc.status & 1) and cost - sc.new_cost > 0:
+                    h.accept(); cost = sc.new_cost; mu *= 0.5
+                    break
+                mu *= nu
+            costs.append(cost)
+        cams, pts = h.get_params()
+        h.close()
+        return np.array(costs), cams, pts
+
+    c0, cams0, pts0 = run(False)
+    c1, cams1, pts1 = run(True)
+    assert c0[-1] < c0[0]
+    # W / PV are written by plain stores in both runs and U / g_a by LDS atomics whose order is
+    # not fixed: agreement to rounding, not bit for bit
+    np.testing.assert_allclose(c1, c0, rtol=1e-12)
+    np.testing.assert_allclose(cams1, cams0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(pts1, pts0, rtol=1e-9, atol=1e-12)
