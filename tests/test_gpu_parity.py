@@ -451,3 +451,26 @@ def test_linearize_ahead_equals_plain_verbs(problems):
     np.testing.assert_allclose(c1, c0, rtol=1e-12)
     np.testing.assert_allclose(cams1, cams0, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(pts1, pts0, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_cams", [3, 5, 6, 11])
+def test_few_cameras(gpu, n_cams):
+    """Edge sizes of the panel chain: a single 32-column panel (<= 5 cameras: only the first
+    diagonal factor, the last-panel trsm and the final mat-vec run), a matrix that just spills
+    into a second panel, and one that ends in a mostly padded panel."""
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=n_cams, n_pts=400, mean_track=min(3.0, n_cams), seed=11 + n_cams,
+                              max_track=n_cams)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    gpu.linearize(1.0, 1.0)
+    gpu.update_UV(mu)
+    close(gpu.compute_S(), sch["S"], 1e-11, "S")
+    ret, dp, _ = o.solve(lin, sch)
+    rc, dpa = gpu.SPDinv_matVec()
+    assert rc == 0 and ret == 0.0
+    close(dpa, dp[: o.nA], 1e-8, "dpa")
+    close(gpu.compute_dpb(), dp, 1e-8, "dp")
