@@ -243,9 +243,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   }
   if (MODE != 0 && keep == 12345.678) sPart[0] = keep;
   __syncthreads();
-  double *slab = p.slab + wg.slab_off;
-  for (int t = tid; t < 36 * wg.nblk; t += SCHUR_THREADS)
-    slab[t] = sPart[BLK_STRIDE * (t / 36) + t % 36];
+  // two doubles per thread and step: 36 is even, so a pair never straddles a block, and the
+  // slab offsets are multiples of 36 * 16 doubles: 16-byte stores
+  double2 *slab = reinterpret_cast<double2 *>(p.slab + wg.slab_off);
+  for (int t = tid; t < 18 * wg.nblk; t += SCHUR_THREADS) {
+    const double *src = sPart + BLK_STRIDE * (t / 18) + 2 * (t % 18);
+    slab[t] = make_double2(src[0], src[1]);
+  }
 }
 
 // writes the padding of the reduce buffer: identity (pad_one = 1 on rank 0, else 0, so that
