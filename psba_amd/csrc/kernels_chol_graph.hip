@@ -514,21 +514,34 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
   if (blockIdx.x == 0) {
     if (tid < 4) s.flag[tid] = 0;
     if (tid == 4) s.fail = 0;
-    if (wave < 2) {  // X of the two tile rows of the next diagonal block
-      d4 xl, xr;
-      trsm_tile(Lw, ld, j, T0 + wave, nT, Li, li, lk, xl, xr);
-      store_x_tile(Lx, ld, j, T0 + wave, li, lk, xl, xr);
+    // the serial part starts here, so its loads are issued together up front (they are first
+    // touches of what other CUs wrote in the previous kernel: ~1 us each if chained): the three
+    // tiles of the next diagonal block, and the operands of the four 16x16 pieces of X (two tile
+    // rows x two column halves, one per wave: 8 MFMAs each)
+    const int tr = (wave > 0), tc = (wave > 1);
+    d4 c = {0, 0, 0, 0};
+    if (wave < 3) c = load_c_tile(Lw, ld, T0 + tr, T0 + tc, li, lk);
+    {
+      const int xr = wave >> 1, half = wave & 1;
+      const Row8 a = load_row8(Lw + (size_t)(16 * (T0 + xr) + li) * ld + j + 8 * lk);
+      const Row8 b = load_row8(Li + (size_t)(16 * half + li) * GB + 8 * lk);
+      d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t], b.v[t], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t + 1], b.v[t + 1], x1, 0, 0, 0);
+      }
+      const d4 x = x0 + x1;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        sX[0][wave][lk + 4 * r][li] = xl[r];
-        sX[0][wave][lk + 4 * r][16 + li] = xr[r];
+        sX[0][xr][lk + 4 * r][16 * half + li] = x[r];
+        Lx[(size_t)(16 * (T0 + xr) + lk + 4 * r) * ld + j + 16 * half + li] = x[r];
       }
     }
     __syncthreads();
     if (wave < 3) {
-      const int tr = (wave > 0), tc = (wave > 1);
       const Row8 a = load_row8(&sX[0][tr][li][8 * lk]), b = load_row8(&sX[0][tc][li][8 * lk]);
-      const d4 c = update_mfma(load_c_tile(Lw, ld, T0 + tr, T0 + tc, li, lk), a, b);
+      c = update_mfma(c, a, b);
 #pragma unroll
       for (int r = 0; r < 4; r++) s.D[16 * tr + lk + 4 * r][16 * tc + li] = c[r];
     }
