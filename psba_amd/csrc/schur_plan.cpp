@@ -50,27 +50,30 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   // ---- camera-row groups by LDS budget: 37 doubles per block, block count padded to 16 ----
   // 100 KiB rather than all 160: smaller partitions mean less slab traffic (flush + reduce),
   // which on venice-shaped outweighs the loss of locality from more groups (scripts/k2_lds_sweep.sh)
-  size_t budget_bytes = 100 * 1024;
-  if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_bytes = (size_t)atoi(e) * 1024;
-  const size_t budget_blocks = budget_bytes / sizeof(double) / 37;
+  // (many cameras: the whole LDS rather than giving up on the schedule)
   std::vector<int> lo;
-  for (int G = 1; G <= MAX_GROUPS && !h->nGroups; G++) {
-    lo.assign(1, 0);
-    for (int g = 1; g < G; g++) {  // equal-area split of the triangle
-      const double target = (double)total_blocks * g / G;
-      int j = lo.back();
-      while (j < nCams && (double)tri(j) < target) j++;
-      if (j <= lo.back()) j = lo.back() + 1;
-      if (j > nCams) j = nCams;
-      lo.push_back(j);
+  for (size_t budget_bytes : {(size_t)100 * 1024, (size_t)159 * 1024}) {
+    if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_bytes = (size_t)atoi(e) * 1024;
+    const size_t budget_blocks = budget_bytes / sizeof(double) / 37;
+    for (int G = 1; G <= MAX_GROUPS && !h->nGroups; G++) {
+      lo.assign(1, 0);
+      for (int g = 1; g < G; g++) {  // equal-area split of the triangle
+        const double target = (double)total_blocks * g / G;
+        int j = lo.back();
+        while (j < nCams && (double)tri(j) < target) j++;
+        if (j <= lo.back()) j = lo.back() + 1;
+        if (j > nCams) j = nCams;
+        lo.push_back(j);
+      }
+      lo.push_back(nCams);
+      bool ok = true;
+      for (int g = 0; g < G && ok; g++) {
+        const long long nb = tri(lo[g + 1]) - tri(lo[g]);
+        ok = lo[g + 1] > lo[g] && (size_t)((nb + ROW - 1) / ROW * ROW) <= budget_blocks && nb <= 1008;
+      }
+      if (ok) h->nGroups = G;
     }
-    lo.push_back(nCams);
-    bool ok = true;
-    for (int g = 0; g < G && ok; g++) {
-      const long long nb = tri(lo[g + 1]) - tri(lo[g]);
-      ok = lo[g + 1] > lo[g] && (size_t)((nb + ROW - 1) / ROW * ROW) <= budget_blocks && nb <= 1008;
-    }
-    if (ok) h->nGroups = G;
+    if (h->nGroups) break;
   }
   if (!h->nGroups) return PSBA_OK;
   const int G = h->nGroups;

@@ -342,11 +342,13 @@ def test_global_atomic_fallback_path(problems, monkeypatch):
     h.close()
 
 
-def test_many_cameras(gpu):
-    """96 cameras (nA = 576: beyond the single-workgroup Cholesky of kernels_chol.hip, 5 LDS
-    groups in K2): the panel-chain solve has no such limit."""
+@pytest.mark.parametrize("n_cams", [96, 200])
+def test_many_cameras(gpu, n_cams):
+    """96 cameras (nA = 576: the largest matrix on the fused panel chain, 16 camera-row groups in
+    K2) and 200 (nA = 1200: two-kernel panels + sequential backward solve, 50 groups with the
+    whole LDS as budget)."""
     import psba_amd.synth as synth
-    prob = synth.make_problem(n_cams=96, n_pts=3000, mean_track=5.0, seed=5)
+    prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=5)
     o = Oracle(prob)
     gpu.upload_problem(prob)
     lin = o.linearize()
