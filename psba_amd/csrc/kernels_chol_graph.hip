@@ -642,24 +642,56 @@ __global__ __launch_bounds__(512) void k_cholg_backward(double *Lw /* the factor
   if (bad) status[1] = status[3];
 }
 
-// dpa = L^-T y: the identity rows of the factor buffer now hold L^-T (row i = e_i^T L^-T, upper
-// triangular), y = L^-1 e_a sits in row n32.  One wave per row, all loads of a lane issued at
-// once (n32 <= 640 on this path: at most ten 64-column strides).
-__global__ __launch_bounds__(256) void k_cholg_solve(const double *Lx, int ld, int n, int n32, double *x,
-                                                    int *status) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
+// dpa = L^-T y: the identity rows of the factor buffer hold L^-T (row i = e_i^T L^-T, upper
+// triangular) for all panels but the last, y = L^-1 e_a sits in row n32.  One wave per row, all
+// loads of a lane issued at once (n32 <= 640 on this path: at most ten 64-column strides).
+// The last panel's trsm is folded in instead of being a kernel of its own: with D the last
+// diagonal block, R_i the last 32 columns of identity row i in the working buffer and r those of
+// the e_a row, the missing part of the sum is (R_i D^-T)(D^-1 r) = R_i w with
+// w = D^-T D^-1 r -- two 32x32 mat-vecs every workgroup does for itself from LDS.
+__global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const double *Lx, int ld, int n, int n32,
+                                                    double *x, const double *linv, int *status) {
+  __shared__ double sLi[GB][GB + 1], sV[GB], sW[GB];
+  const int tid = threadIdx.x, lane = tid & 63, i = blockIdx.x * 4 + (tid >> 6);
+  const int jl = n32 - GB;  // first column of the last panel
+  const double *Li = linv + (size_t)(jl / GB) * GB * GB;
+  for (int t = tid; t < GB * GB; t += 256) sLi[t / GB][t % GB] = Li[t];
+  const double rk = tid < GB ? Lw[(size_t)n32 * ld + jl + tid] : 0.0;
+  // the main part of the row's sum is in flight while w is formed
+  const bool row = i < n;
   const double *y = Lx + (size_t)n32 * ld;
-  const double *z = Lx + (size_t)(n32 + 16 + i) * ld;
+  const double *z = Lx + (size_t)(n32 + 16 + (row ? i : 0)) * ld;
   double zv[10], yv[10];
 #pragma unroll
   for (int m = 0; m < 10; m++) {
     const int c = lane + 64 * m;
-    const bool on = c < n32 && c >= (i & ~15);  // left of the diagonal tile: zeros, never written
+    const bool on = row && c < jl && c >= (i & ~15);  // left of the diagonal tile: zeros, never written
     zv[m] = on ? z[c] : 0.0;
     yv[m] = on ? y[c] : 0.0;
   }
-  double acc = 0.0;
+  double rt = 0.0;  // R_i[k]: generated for the rows of the last panel's own column block
+  if (row && lane < GB) rt = i >= jl ? (double)(lane == i - jl) : Lw[(size_t)(n32 + 16 + i) * ld + jl + lane];
+  if (tid < GB) sV[tid] = rk;
+  __syncthreads();
+  double v = 0.0;
+  if (tid < GB) {  // D^-1 r, four independent chains
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < GB; k++) a4[k & 3] += sLi[tid][k] * sV[k];
+    v = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
+  __syncthreads();
+  if (tid < GB) sV[tid] = v;
+  __syncthreads();
+  if (tid < GB) {
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};  // D^-T (D^-1 r)
+#pragma unroll
+    for (int c = 0; c < GB; c++) a4[c & 3] += sLi[c][tid] * sV[c];
+    sW[tid] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
+  __syncthreads();
+  if (!row) return;
+  double acc = lane < GB ? rt * sW[lane] : 0.0;
 #pragma unroll
   for (int m = 0; m < 10; m++) acc += zv[m] * yv[m];
 #pragma unroll
@@ -683,9 +715,10 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;
     const long long M = (nT - 1) - T0;
+    if (last && fused) break;  // the last panel's trsm is part of k_cholg_solve
     if (last || !fused) {
-      // 16-row tiles below the panel incl. the e_a tile (+ all identity tile rows at the end)
-      const int nTall = (last && fused) ? nT + n32 / 16 : nT;
+      // 16-row tiles below the panel incl. the e_a tile
+      const int nTall = nT;
       hipLaunchKernelGGL(k_cholg_trsm, dim3((nTall - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nTall, linv);
       if (!last) {
         const int grid = 1 + (int)((M * (M + 1) / 2 + M - 3 + 3) / 4);
@@ -697,8 +730,8 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s) {
     }
   }
   if (fused) {
-    hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lx, ld, h->d.nA, n32, h->dp,
-                       h->status);
+    hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
+                       linv, h->status);
   } else {
     int thr = (n32 + 63) / 64 * 64;
     if (thr > 512) thr = 512;
