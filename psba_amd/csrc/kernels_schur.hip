@@ -12,6 +12,7 @@
 // block triangle of S (cameras ascend inside a point).  k_schur_finalize adds U + mu I and
 // g_a and mirrors the upper block triangle.
 #include "camera_model.h"
+#include "chol_factor32.h"
 #include <cstdlib>
 
 #include "psba_internal.h"
@@ -145,6 +146,11 @@ struct SchurLdsArgs {
   double *dbg_Y, *dbg_Vinv;
   double mu;
   int nWg, try_id;
+  // single rank: while flushing, a workgroup also adds its copies of the blocks (j, k), j <= 5
+  // (the first 32x32 diagonal block of S) into diag0 with global atomics, so that the S-reduce
+  // kernel can factor that block without gathering it from all the slabs
+  double *diag0;           // nullptr: off
+  int diag_grp[21], diag_pos[21];
 };
 
 __device__ __forceinline__ int tri(int j) { return j * (j + 1) / 2; }
@@ -250,6 +256,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
     const double *src = sPart + BLK_STRIDE * (t / 18) + 2 * (t % 18);
     slab[t] = make_double2(src[0], src[1]);
   }
+  if (p.diag0 && tid < 21 * 36) {
+    const int b = tid / 36, rc = tid % 36;
+    if (p.diag_grp[b] == wg.group) {
+      const double v = sPart[BLK_STRIDE * p.diag_pos[b] + rc];
+      if (v != 0.0) atomicAdd(&p.diag0[tid], v);
+    }
+  }
 }
 
 // writes the padding of the reduce buffer: identity (pad_one = 1 on rank 0, else 0, so that
@@ -284,6 +297,12 @@ struct SchurReduceArgs {
   int nA, n32, nGroups, try_id;
   int gnwg[MAX_GROUPS], gnblk[MAX_GROUPS], gpos0[MAX_GROUPS + 1];  // gpos0: first position of a group
   unsigned long long gslab[MAX_GROUPS];
+  // single rank: workgroup diag_wg (one past the regular ones, -1: off) takes the first 32x32
+  // diagonal block of S as summed into diag0 by the K2 workgroups, factors it (the first step
+  // of the Cholesky chain: otherwise a kernel of its own with one CU busy and 255 idle) and
+  // clears diag0 for the next try
+  int diag_wg;
+  double *diag0, *Lx, *linv;
 };
 
 // sums the slabs of each camera-row group (fixed order: four interleaved slab sequences, then
@@ -291,14 +310,49 @@ struct SchurReduceArgs {
 // block triangles) and the e_a row.  Workgroups walk the slabs in storage order (64
 // consecutive doubles x 4 slab sequences each; a group's partition is a multiple of 576
 // doubles, so a workgroup never straddles groups) and scatter the few results.
+__device__ __forceinline__ void reduce_first_diag_block(const SchurReduceArgs &p, Factor32Lds &s) {
+  const int tid = threadIdx.x, nC = p.nA / 6;
+  if (tid < 4) s.flag[tid] = 0;
+  if (tid == 4) s.fail = 0;
+  for (int t = tid; t < GB * GB; t += 256) s.D[t / GB][t % GB] = (t / GB == t % GB) ? 1.0 : 0.0;  // padding
+  __syncthreads();
+  for (int e = tid; e < 21 * 36; e += 256) {
+    const double sum = p.diag0[e];
+    p.diag0[e] = 0.0;
+    const int blk = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
+    const int j = blk < 1 ? 0 : blk < 3 ? 1 : blk < 6 ? 2 : blk < 10 ? 3 : blk < 15 ? 4 : 5, k = blk - tri(j);
+    const int row = 6 * j + r, col = 6 * k + c;
+    if (j >= nC || row >= GB || col >= GB || (j == k && c > r)) continue;
+    double acc = sum;
+    if (j == k) {
+      acc += p.U[36 * j + rc];
+      if (r == c) acc += p.mu_add;
+    }
+    s.D[row][col] = acc;
+  }
+  __syncthreads();
+  factor32(s, tid);
+  for (int t = tid; t < GB * GB; t += 256) {
+    const int r = t / GB, c = t % GB;
+    p.Lx[(size_t)r * p.n32 + c] = f32_L(s, r, c);
+    p.linv[t] = f32_Linv(s, r, c);
+  }
+  if (tid == 0 && s.fail) p.status[1] = p.try_id;
+}
+
 __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   __shared__ double sAcc[4][64];
+  __shared__ Factor32Lds sF;
+  if ((int)blockIdx.x == p.diag_wg) {
+    reduce_first_diag_block(p, sF);
+    return;
+  }
   // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
   // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
   if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) p.scal[SC_PART + threadIdx.x] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 64) p.status[3] = p.try_id;
   write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
-                (size_t)gridDim.x * blockDim.x);
+                (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + o;  // slot 36 * (global position) + rc
   int g = 0;
@@ -383,6 +437,19 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   a.mu = mu;
   a.nWg = h->nWg;
   a.try_id = h->try_id;
+  // the first diagonal block can be factored beside the S-reduce only if S is complete on this rank
+  const bool fuse_diag = h->nranks == 1 && h->diag0 && !getenv("PSBA_CHOL_SEPARATE_DIAG");
+  a.diag0 = fuse_diag ? h->diag0 : nullptr;
+  for (int j = 0, b = 0; j < 6; j++)
+    for (int k = 0; k <= j; k++, b++) {
+      int g = -1;
+      if (j < d.nC) {
+        g = 0;
+        while (j >= h->glo[g + 1]) g++;
+      }
+      a.diag_grp[b] = g;
+      a.diag_pos[b] = h->h_diagpos[b];
+    }
   SchurReduceArgs r;
   r.slab = h->slab;
   r.U = h->U;
@@ -398,6 +465,9 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   r.n32 = h->n32;
   r.nGroups = h->nGroups;
   r.try_id = h->try_id;
+  r.diag0 = h->diag0;
+  r.Lx = h->chol_L;
+  r.linv = h->chol_ws;
   int worst = 0;
   r.gpos0[0] = 0;
   for (int g = 0; g < h->nGroups; g++) {
@@ -409,6 +479,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   }
   const size_t lds = sizeof(double) * BLK_STRIDE * (size_t)worst;
   const int rgrid = 36 * r.gpos0[h->nGroups] / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
+  r.diag_wg = fuse_diag ? rgrid : -1;
   {
     ProfScope ps(h, PSBA_K_SCHUR);
     const char *m = getenv("PSBA_SCHUR_MODE");
@@ -430,8 +501,9 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   PSBA_HIP(h, hipGetLastError());
   {
     ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
-    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid), dim3(256), 0, h->stream, r);
+    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid + (r.diag_wg >= 0 ? 1 : 0)), dim3(256), 0, h->stream, r);
   }
+  h->diag_done = r.diag_wg >= 0;
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
 }
@@ -439,7 +511,8 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
 static bool g_lds_attr_set = false;
 
 int launch_schur(psba_ctx *h, double mu, bool dump) {
-  h->try_id++;  // status words are generation stamps: nothing to zero
+  h->try_id++;
+  h->diag_done = false;  // status words are generation stamps: nothing to zero
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
     if (!g_lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition

@@ -83,10 +83,11 @@ static void dev_free(T *&p) {
 }
 
 static void free_problem_buffers(psba_ctx *h) {
-  if (h->chol_graph) {
-    (void)hipGraphExecDestroy(h->chol_graph);
-    h->chol_graph = nullptr;
-  }
+  for (int v = 0; v < 2; v++)
+    if (h->chol_graph[v]) {
+      (void)hipGraphExecDestroy(h->chol_graph[v]);
+      h->chol_graph[v] = nullptr;
+    }
   dev_free(h->camconst);
   dev_free(h->cams[0]);
   dev_free(h->cams[1]);
@@ -111,6 +112,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->items);
   dev_free(h->wg);
   dev_free(h->posblock);
+  dev_free(h->diag0);
   dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->chol_ws);
@@ -291,6 +293,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       PSBA_HIP(h, hipMemcpy(h->items, plan.items.data(), sizeof(unsigned long long) * plan.items.size(), hipMemcpyHostToDevice));
       PSBA_HIP(h, hipMemcpy(h->wg, plan.wgs.data(), sizeof(SchurWg) * plan.wgs.size(), hipMemcpyHostToDevice));
       PSBA_HIP(h, hipMemcpy(h->posblock, plan.posblock.data(), sizeof(int) * plan.posblock.size(), hipMemcpyHostToDevice));
+      for (int j = 0, b = 0; j < 6; j++)
+        for (int k = 0; k <= j; k++, b++) h->h_diagpos[b] = j < nCams ? plan.blockpos[(size_t)j * (j + 1) / 2 + k] : 0;
+      TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
+      PSBA_HIP(h, hipMemset(h->diag0, 0, sizeof(double) * 21 * 36));
       if (getenv("PSBA_SCHUR_PLAN_INFO"))
         fprintf(stderr, "[psba] K2 plan: %d groups, %d workgroups, %lld products in %zu item slots (fill %.3f), slabs %.1f MB\n",
                 h->nGroups, h->nWg, plan.real_items, plan.items.size(),
@@ -800,6 +806,7 @@ int psba_set_reduce_buffer(psba_handle h, const double *in) {
   PSBA_HIP(h, hipMemcpyAsync(h->red, in, sizeof(double) * (size_t)(h->n32 + 1) * h->n32,
                              hipMemcpyHostToDevice, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  h->diag_done = false;  // S changed under the factor of its first diagonal block
   return PSBA_OK;
 }
 

@@ -103,13 +103,19 @@ struct psba_ctx {
   size_t gslab[psba::MAX_GROUPS] = {0};  // first double of group g's slabs
   psba::SchurWg *wg = nullptr;  // [nWg] ordered by position in the point sequence
   unsigned long long *items = nullptr;   // work items, one per product Y_a W_b^T (or null)
+  // single rank: the K2 workgroups add their copies of the 21 blocks of the first 32x32 diagonal
+  // block into diag0 (global atomics) while flushing, and one extra workgroup of the S-reduce
+  // kernel factors that block -- the first step of the Cholesky chain off the critical path
+  double *diag0 = nullptr;      // [21 * 36], zero between tries
+  int h_diagpos[21] = {0};      // partition positions of the blocks (j, k), j <= 5
+  bool diag_done = false;       // this try's S-reduce kernel has factored the first diagonal block
   int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
-  hipGraphExec_t chol_graph = nullptr;  // captured panel chain of kernels_chol_graph.hip
-  int chol_graph_n32 = 0;
-  double *chol_graph_red = nullptr;
+  hipGraphExec_t chol_graph[2] = {nullptr, nullptr};  // captured panel chain of kernels_chol_graph.hip, with / without its first step
+  int chol_graph_n32[2] = {0, 0};
+  double *chol_graph_red[2] = {nullptr, nullptr};
   long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
   double *chol_L = nullptr;     // [(2 n32+16)][n32] panel chain: the Cholesky factor | forward-solved e_a row | L^-T
   double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
