@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import psba_amd  # noqa: E402  (loads the HIP library before torch brings its own runtime)
 from psba_amd import capi, synth  # noqa: E402
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (= matrix) peak
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -193,6 +194,15 @@ def main():
                          "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
                          "traffic": None},
         }
+        # SURVEY 8(d) also asks for the kernel's FP64 rate: nP*50 (V^-1) + nO*(108 Y + 36 e_a) +
+        # P_sym*216 flops per launch, P_sym = sum_i k_i (k_i + 1) / 2 products
+        ii = np.asarray(prob["iidx"])
+        k = np.bincount(ii, minlength=int(prob["nP"])).astype(np.int64)
+        sch_flops = float(int(prob["nP"]) * 50 + int(prob["nO"]) * 144 + int((k * (k + 1) // 2).sum()) * 216)
+        out["roofline"]["fp64"] = {"algorithmic_flops_per_launch": sch_flops,
+                                   "achieved": sch_flops / (sch_us * 1e-6) / 1e12 if sch_us > 0 else None,
+                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": sch_flops / (sch_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if sch_us > 0 else None}
         tr = pmc_traffic(args.workload) if world == 1 else None
         if tr:
             out["roofline"]["traffic"] = tr[0]
