@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 import psba_amd  # noqa: E402  (loads the HIP library before torch brings its own runtime)
 from psba_amd import capi, synth  # noqa: E402
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (= matrix) peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure quoted in SURVEY.md 8(d): fp64 vector (= matrix) peak; = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
