@@ -202,9 +202,12 @@ __device__ __forceinline__ d16 f32_inverse16(Factor32Lds &s, int lane) {
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; k++) {
       const int r = 4 * p + k;
-      double v = (r == c) ? 1.0 : 0.0;
+      // four partial sums: the wave runs alone on its SIMD, so a single chain of up to 15
+      // dependent fma would cost ~16 cycles a link, most of it in the tail behind the pivot wave
+      double sm[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma clang loop unroll(full)
-      for (int m = 0; m < r; m++) v -= s.D[O + r][O + m] * x[m];
+      for (int m = 0; m < r; m++) sm[m & 3] += s.D[O + r][O + m] * x[m];
+      const double v = ((r == c) ? 1.0 : 0.0) - ((sm[0] + sm[1]) + (sm[2] + sm[3]));
       const double xr = v * s.rinv[O + r];  // 1 / D[r][r]
       x[r] = xr;
       // pin the row here: otherwise the compiler sinks the arithmetic below the last wait and
