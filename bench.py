@@ -143,7 +143,7 @@ def main():
     h.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    steps_done, tries_done, res = run_steps(args.steps)  # every levmar call returns synchronised
+    steps_done, tries_done, res = run_steps(args.steps)  # every levmar call returns with its stream drained
     t1 = time.perf_counter()
     barrier()
     elapsed = t1 - t0

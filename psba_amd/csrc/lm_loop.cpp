@@ -63,7 +63,7 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
       // :151-157,185-193 -- and, while the host looks at the scalars, the next iteration's
       // linearization at the proposed parameters (dropped if the step is rejected)
       LM_TRY(psba_backsub_async(h, mu));
-      LM_TRY(psba_linearize_ahead(h));
+      if (itno + 1 < opts->max_iter) LM_TRY(psba_linearize_ahead(h));  // no iteration left to use it otherwise
       LM_TRY(psba_backsub_wait(h, &sc));
       if (!(sc.status & PSBA_NOT_SPD)) {
         dp_L2 = sc.dp_l2;
@@ -120,6 +120,9 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
     if (ex_L2 <= STOP) flag = PSBA_ITER_ERR_SMALL_ENOUGH;  // :247-248
   }
 #undef LM_TRY
+  // nothing of this call is left on the device when it returns (a linearization computed ahead
+  // for a step that was then not taken may still be running)
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return PSBA_E_HIP;
   res->flag = flag;
   res->iters = itno;
   res->tries = tries;
