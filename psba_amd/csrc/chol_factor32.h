@@ -165,11 +165,18 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
 #pragma clang loop unroll(full)
   for (int p = 0; p < 6; p++) {  // panel p+2 <= 7 is the last one to stage
     const int j0 = 4 * p;
-    f32_wait(&s.flag[0], p + 1);
-    // rank-4 update A -= (D / d) D^T: one operand scaled by 1 / d_k, k = this lane's k slot
-    const double a1 = s.D[16 + col][j0 + rc], nr = -s.rinv[j0 + rc];
+    // rank-4 update A -= (D / d) D^T: one operand scaled by 1 / d_k, k = this lane's k slot.
+    // Flag and operands are read in one batch (volatile: issued in this order; a wave's LDS
+    // reads complete in order), so a published panel costs one LDS round trip, not two
+    double a0 = 0.0, a1, nr;
+    int f;
+    do {
+      f = *(volatile lds_int *)&s.flag[0];
+      a1 = *(volatile lds_double *)&s.D[16 + col][j0 + rc];
+      nr = -*(volatile lds_double *)&s.rinv[j0 + rc];
+      if (p < 2) a0 = *(volatile lds_double *)&s.D[col][j0 + rc];
+    } while (f < p + 1);
     if (p < 2) {  // columns < 16 are staged for panels 2, 3 only
-      const double a0 = s.D[col][j0 + rc];
       T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * nr, a0, T00, 0, 0, 0);
       T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * nr, a0, T10, 0, 0, 0);
     }
