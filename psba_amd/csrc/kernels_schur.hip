@@ -303,6 +303,10 @@ struct SchurReduceArgs {
   // clears diag0 for the next try
   int diag_wg;
   double *diag0, *Lx, *linv;
+  // with a communicator: the sums (U, mu on rank 0 and g_a folded in) go to `packed` in slab
+  // order instead of into S -- the lower block triangle and e_a only, half the bytes of the square
+  // -- and k_schur_expand scatters them after the all-reduce
+  double *packed;
 };
 
 // sums the slabs of each camera-row group (fixed order: four interleaved slab sequences, then
@@ -351,8 +355,9 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
   if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) p.scal[SC_PART + threadIdx.x] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 64) p.status[3] = p.try_id;
-  write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
-                (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
+  if (!p.packed)
+    write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + o;  // slot 36 * (global position) + rc
   int g = 0;
@@ -378,21 +383,63 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   if (q != 0) return;
   acc = ((sAcc[0][o] + sAcc[1][o]) + sAcc[2][o]) + sAcc[3][o];
   const int jk = p.posblock[e / 36];
-  if (jk < 0) return;
   const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
-  if (j == jb) {
-    // a diagonal block holds its lower triangle; six upper slots carry e_a, the rest is unused
-    if (c > r) {
+  int ea_slot = -1;  // a diagonal block holds its lower triangle; six upper slots carry e_a, the rest is unused
+  if (jk >= 0 && j == jb && c > r) {
 #pragma unroll
-      for (int t = 0; t < 6; t++)
-        if (rc == EA_SLOT[t]) p.ea[6 * j + t] = p.ga[6 * j + t] + acc;
-      return;
+    for (int t = 0; t < 6; t++)
+      if (rc == EA_SLOT[t]) ea_slot = t;
+  }
+  const bool unused = jk < 0 || (j == jb && c > r && ea_slot < 0);
+  if (!unused) {
+    if (ea_slot >= 0) {
+      acc += p.ga[6 * j + ea_slot];
+    } else if (j == jb) {
+      acc += p.U[36 * j + rc];
+      if (r == c) acc += p.mu_add;
     }
-    acc += p.U[36 * j + rc];
-    if (r == c) acc += p.mu_add;
+  }
+  if (p.packed) {
+    p.packed[e] = unused ? 0.0 : acc;
+    return;
+  }
+  if (unused) return;
+  if (ea_slot >= 0) {
+    p.ea[6 * j + ea_slot] = acc;
+    return;
   }
   p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = acc;
   p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = acc;
+}
+
+// after the all-reduce of the packed sums: scatter them into the padded row-major S (both block
+// triangles) and the e_a row, and write the identity padding
+__global__ __launch_bounds__(256) void k_schur_expand(const double *packed, const int *posblock, int total,
+                                                      double *S, double *ea, int nA, int n32) {
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  write_padding(S, nA, n32, 1.0, gtid, (size_t)gridDim.x * blockDim.x);
+  const int e = (int)gtid;
+  if (e >= total) return;
+  const int jk = posblock[e / 36];
+  if (jk < 0) return;
+  const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
+  const double v = packed[e];
+  if (j == jb && c > r) {
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+      if (rc == EA_SLOT[t]) ea[6 * j + t] = v;
+    return;
+  }
+  S[(size_t)(6 * jb + c) * n32 + 6 * j + r] = v;
+  S[(size_t)(6 * j + r) * n32 + 6 * jb + c] = v;
+}
+
+int launch_schur_expand(psba_ctx *h) {
+  const int total = (int)h->packed_doubles;
+  hipLaunchKernelGGL(k_schur_expand, dim3((total + 255) / 256), dim3(256), 0, h->stream, h->redp, h->posblock,
+                     total, h->red, h->red + (size_t)h->n32 * h->n32, h->d.nA, h->n32);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
 }
 
 // (v1 path) S += blockdiag(U) + mu_add I on the lower block triangle, mirror to the upper
@@ -466,6 +513,8 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   r.nGroups = h->nGroups;
   r.try_id = h->try_id;
   r.diag0 = h->diag0;
+  r.packed = h->comm ? h->redp : nullptr;
+  h->packed_pending = r.packed != nullptr;
   r.Lx = h->chol_L;
   r.linv = h->chol_ws;
   int worst = 0;
@@ -512,7 +561,8 @@ static bool g_lds_attr_set = false;
 
 int launch_schur(psba_ctx *h, double mu, bool dump) {
   h->try_id++;
-  h->diag_done = false;  // status words are generation stamps: nothing to zero
+  h->diag_done = false;
+  h->packed_pending = false;  // status words are generation stamps: nothing to zero
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
     if (!g_lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition

@@ -113,6 +113,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->wg);
   dev_free(h->posblock);
   dev_free(h->diag0);
+  dev_free(h->redp);
   dev_free(h->slab);
   dev_free(h->dp);
   dev_free(h->chol_ws);
@@ -295,6 +296,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       PSBA_HIP(h, hipMemcpy(h->posblock, plan.posblock.data(), sizeof(int) * plan.posblock.size(), hipMemcpyHostToDevice));
       for (int j = 0, b = 0; j < 6; j++)
         for (int k = 0; k <= j; k++, b++) h->h_diagpos[b] = j < nCams ? plan.blockpos[(size_t)j * (j + 1) / 2 + k] : 0;
+      h->packed_doubles = plan.posblock.size() * 36;
+      TRY(dev_alloc(h, &h->redp, h->packed_doubles));
       TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
       PSBA_HIP(h, hipMemset(h->diag0, 0, sizeof(double) * 21 * 36));
       if (getenv("PSBA_SCHUR_PLAN_INFO"))
@@ -423,19 +426,34 @@ int psba_schur_assemble(psba_handle h, double mu) {
   return PSBA_OK;
 }
 
+// the per-try collective: [tril(S) || e_a] in slab order when the LDS schedule produced it
+// (about half the bytes of the padded square), then scattered into the padded buffer; the whole
+// padded square for the global-atomic fallback kernel
+static int allreduce_schur(psba_ctx *h) {
+  if (h->packed_pending) {
+    RCCL(h, ncclAllReduce(h->redp, h->redp, h->packed_doubles, ncclDouble, ncclSum, h->comm, h->stream));
+    TRY(launch_schur_expand(h));
+    h->packed_pending = false;
+  } else {
+    const size_t n = (size_t)(h->n32 + 1) * h->n32;  // S rows, padding rows and the ea row
+    RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
+  }
+  return PSBA_OK;
+}
+
 int psba_schur_reduce(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
   if (!h->comm) return PSBA_OK;
   ProfScope ps(h, PSBA_K_ALLREDUCE);
-  const size_t n = (size_t)(h->n32 + 1) * h->n32;  // S rows, padding rows and the ea row
-  RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
+  TRY(allreduce_schur(h));
   return PSBA_OK;
 }
 
 int psba_schur_solve(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
+  if (h->packed_pending) TRY(allreduce_schur(h));  // psba_schur_reduce was skipped
   TRY(launch_chol_solve(h));
   if (h->chol_tim) {
     long long t[16];
@@ -554,10 +572,7 @@ static int reassemble_dump(psba_ctx *h) {
   TRY(launch_schur(h, h->mu_applied ? h->mu : 0.0, true));
   h->assembled = true;
   h->solved = h->backsubbed = false;
-  if (h->comm) {
-    const size_t n = (size_t)(h->n32 + 1) * h->n32;
-    RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
-  }
+  if (h->comm) TRY(allreduce_schur(h));
   return PSBA_OK;
 }
 
@@ -796,12 +811,14 @@ int psba_reduce_buffer_size(psba_handle h, long long *n_doubles) {
 int psba_get_reduce_buffer(psba_handle h, double *out) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
+  NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
   return d2h(h, out, h->red, sizeof(double) * (size_t)(h->n32 + 1) * h->n32);
 }
 
 int psba_set_reduce_buffer(psba_handle h, const double *in) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
+  NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
   if (!in) return fail(h, PSBA_E_INVALID, "null buffer");
   PSBA_HIP(h, hipMemcpyAsync(h->red, in, sizeof(double) * (size_t)(h->n32 + 1) * h->n32,
                              hipMemcpyHostToDevice, h->stream));

@@ -106,6 +106,9 @@ struct psba_ctx {
   // single rank: the K2 workgroups add their copies of the 21 blocks of the first 32x32 diagonal
   // block into diag0 (global atomics) while flushing, and one extra workgroup of the S-reduce
   // kernel factors that block -- the first step of the Cholesky chain off the critical path
+  double *redp = nullptr;       // with a communicator: the packed sums (slab order, lower block triangle + e_a) that are all-reduced
+  size_t packed_doubles = 0;
+  bool packed_pending = false;  // this try's sums sit in redp, not yet in red
   double *diag0 = nullptr;      // [21 * 36], zero between tries
   int h_diagpos[21] = {0};      // partition positions of the blocks (j, k), j <= 5
   bool diag_done = false;       // this try's S-reduce kernel has factored the first diagonal block
@@ -175,6 +178,7 @@ int launch_max_diag(psba_ctx *h);
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
                      const int *ptr, SchurPlanHost &out);
 int launch_schur(psba_ctx *h, double mu, bool dump);
+int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip
 int launch_chol_solve(psba_ctx *h);
 // kernels_chol_graph.hip
