@@ -413,32 +413,94 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
 }
 
 // after the all-reduce of the packed sums: scatter them into the padded row-major S (both block
-// triangles) and the e_a row, and write the identity padding
-__global__ __launch_bounds__(256) void k_schur_expand(const double *packed, const int *posblock, int total,
-                                                      double *S, double *ea, int nA, int n32) {
+// triangles) and the e_a row, and write the identity padding.  One extra workgroup (diag_wg)
+// picks the first 32x32 diagonal block out of the packed sums and factors it -- as on a single
+// rank, the first step of the Cholesky chain runs beside a kernel that is needed anyway.
+struct SchurExpandArgs {
+  const double *packed;
+  const int *posblock;
+  double *S, *ea, *Lx, *linv;
+  int *status;
+  int total, nA, n32, try_id, diag_wg;
+  int diag_slot[21];  // 36 * (global position) of block (j, k), j <= 5
+};
+
+__global__ __launch_bounds__(256) void k_schur_expand(SchurExpandArgs p) {
+  __shared__ Factor32Lds sF;
+  if ((int)blockIdx.x == p.diag_wg) {
+    const int tid = threadIdx.x, nC = p.nA / 6;
+    if (tid < 4) sF.flag[tid] = 0;
+    if (tid == 4) sF.fail = 0;
+    for (int t = tid; t < GB * GB; t += 256) sF.D[t / GB][t % GB] = (t / GB == t % GB) ? 1.0 : 0.0;  // padding
+    __syncthreads();
+    for (int e = tid; e < 21 * 36; e += 256) {
+      const int blk = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
+      const int j = blk < 1 ? 0 : blk < 3 ? 1 : blk < 6 ? 2 : blk < 10 ? 3 : blk < 15 ? 4 : 5, k = blk - tri(j);
+      const int row = 6 * j + r, col = 6 * k + c;
+      if (j >= nC || row >= GB || col >= GB || (j == k && c > r)) continue;
+      sF.D[row][col] = p.packed[p.diag_slot[blk] + rc];  // U, mu already folded in
+    }
+    __syncthreads();
+    factor32(sF, tid);
+    for (int t = tid; t < GB * GB; t += 256) {
+      const int r = t / GB, c = t % GB;
+      p.Lx[(size_t)r * p.n32 + c] = f32_L(sF, r, c);
+      p.linv[t] = f32_Linv(sF, r, c);
+    }
+    if (tid == 0 && sF.fail) p.status[1] = p.try_id;
+    return;
+  }
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  write_padding(S, nA, n32, 1.0, gtid, (size_t)gridDim.x * blockDim.x);
+  write_padding(p.S, p.nA, p.n32, 1.0, gtid, (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
   const int e = (int)gtid;
-  if (e >= total) return;
-  const int jk = posblock[e / 36];
+  if (e >= p.total) return;
+  const int jk = p.posblock[e / 36];
   if (jk < 0) return;
   const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
-  const double v = packed[e];
+  const double v = p.packed[e];
   if (j == jb && c > r) {
 #pragma unroll
     for (int t = 0; t < 6; t++)
-      if (rc == EA_SLOT[t]) ea[6 * j + t] = v;
+      if (rc == EA_SLOT[t]) p.ea[6 * j + t] = v;
     return;
   }
-  S[(size_t)(6 * jb + c) * n32 + 6 * j + r] = v;
-  S[(size_t)(6 * j + r) * n32 + 6 * jb + c] = v;
+  p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = v;
+  p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = v;
 }
 
 int launch_schur_expand(psba_ctx *h) {
-  const int total = (int)h->packed_doubles;
-  hipLaunchKernelGGL(k_schur_expand, dim3((total + 255) / 256), dim3(256), 0, h->stream, h->redp, h->posblock,
-                     total, h->red, h->red + (size_t)h->n32 * h->n32, h->d.nA, h->n32);
+  SchurExpandArgs a;
+  a.packed = h->redp;
+  a.posblock = h->posblock;
+  a.S = h->red;
+  a.ea = h->red + (size_t)h->n32 * h->n32;
+  a.Lx = h->chol_L;
+  a.linv = h->chol_ws;
+  a.status = h->status;
+  a.total = (int)h->packed_doubles;
+  a.nA = h->d.nA;
+  a.n32 = h->n32;
+  a.try_id = h->try_id;
+  const int grid = (a.total + 255) / 256;
+  const bool fuse = !h->diag_done && !getenv("PSBA_CHOL_SEPARATE_DIAG");
+  a.diag_wg = fuse ? grid : -1;
+  int gpos0 = 0, gp[MAX_GROUPS + 1];
+  for (int g = 0; g < h->nGroups; g++) {
+    gp[g] = gpos0;
+    gpos0 += h->gnblk[g];
+  }
+  for (int j = 0, b = 0; j < 6; j++)
+    for (int k = 0; k <= j; k++, b++) {
+      a.diag_slot[b] = 0;
+      if (j < h->d.nC) {
+        int g = 0;
+        while (j >= h->glo[g + 1]) g++;
+        a.diag_slot[b] = 36 * (gp[g] + h->h_diagpos[b]);
+      }
+    }
+  hipLaunchKernelGGL(k_schur_expand, dim3(grid + (fuse ? 1 : 0)), dim3(256), 0, h->stream, a);
   PSBA_HIP(h, hipGetLastError());
+  if (fuse) h->diag_done = true;
   return PSBA_OK;
 }
 
@@ -485,7 +547,10 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   a.nWg = h->nWg;
   a.try_id = h->try_id;
   // the first diagonal block can be factored beside the S-reduce only if S is complete on this rank
-  const bool fuse_diag = h->nranks == 1 && h->diag0 && !getenv("PSBA_CHOL_SEPARATE_DIAG");
+  // (PSBA_SCHUR_NO_FLUSH_DIAG: test hook -- a single-rank communicator then takes the multi-rank
+  // route, where k_schur_expand factors the block after the all-reduce)
+  const bool fuse_diag = h->nranks == 1 && h->diag0 && !getenv("PSBA_CHOL_SEPARATE_DIAG") &&
+                         !getenv("PSBA_SCHUR_NO_FLUSH_DIAG");
   a.diag0 = fuse_diag ? h->diag0 : nullptr;
   for (int j = 0, b = 0; j < 6; j++)
     for (int k = 0; k <= j; k++, b++) {
