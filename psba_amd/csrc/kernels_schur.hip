@@ -6,11 +6,17 @@
 // restore_UVdiag.cl:2-25) and their wrappers PSBA/sba_func.cpp:624-995.
 //
 // mu is added in registers (U, V are never modified, so nothing is restored); V^-1 and Y
-// are never written to HBM.  Point-major: a tile of whole points is staged in LDS (its W
-// blocks, V^-1, g_b), each thread owns one observation a, forms Y_a in registers and emits
-// the products Y_a W_b^T for every observation b <= a of the same point, i.e. the lower
-// block triangle of S (cameras ascend inside a point).  k_schur_finalize adds U + mu I and
-// g_a and mirrors the upper block triangle.
+// are never written to HBM.  The kernels, in launch order:
+//   k_schur_lds     one product Y_a W_b^T (b <= a, same point) per thread from the static
+//                   schedule of schur_plan.cpp, accumulated in LDS partitions of the lower block
+//                   triangle of S (cameras ascend inside a point), flushed as one slab per
+//                   workgroup;
+//   k_schur_reduce  sums the slabs, folds in U + mu I and g_a, and writes the padded S (both
+//                   block triangles) and the e_a row -- or, with a communicator, the packed
+//                   [tril(S) | e_a] that is all-reduced and then scattered by k_schur_expand;
+//                   one extra workgroup factors the first 32x32 diagonal block (chol_factor32.h);
+//   k_schur_atomic + k_schur_finalize   the first-generation path (global fp64 atomics straight
+//                   into S), kept as the fallback for camera counts the LDS schedule cannot hold.
 #include "camera_model.h"
 #include "chol_factor32.h"
 #include <cstdlib>
