@@ -134,7 +134,9 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
         for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= t[k] * readlane_f64g(a[k], j0 + k2);
       }
     }
-    if (q == 0) f32_wait(&s.flag[2], 1);  // the tile wave reads the original block first
+    // the tile wave reads the original block first -- but only its columns >= 8 ever leave the
+    // tiles again (panels 0 and 1 are read here, from s.D), so the first two panels need not wait
+    if (q == 2) f32_wait(&s.flag[2], 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) s.D[row][j0 + k] = a[k];  // lanes 32..63 repeat lanes 0..31
     if (lane == 0) {
