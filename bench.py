@@ -126,14 +126,23 @@ def main():
         done = tries = 0
         res = None
         while done < n:
+            ts = time.perf_counter()
             h.set_params(cams0, pts0)
             res, _ = h.levmar(max_iter=min(args.segment, n - done), tr_handoff=False, log_cap=0)
+            if os.environ.get("PSBA_BENCH_DEBUG"):
+                print(f"[bench] segment of {res.iters}: {1e6 * (time.perf_counter() - ts):.1f} us", file=sys.stderr)
             if res.iters == 0:
                 raise SystemExit("LM made no iteration: cannot time steps")
             done += res.iters
             tries += res.tries
         return done, tries, res
 
+    # device wake-up, before the W warm-up steps: the first ~6 ms of sustained load on a fresh
+    # process run at a lower clock and end in a ~0.8 ms stall when the clock steps up (seen as one
+    # slow segment, then ~3 % faster ones: PSBA_BENCH_DEBUG=1 prints the segment times).  Sixty
+    # untimed LM iterations put that transition behind us whatever W and K are.
+    if not os.environ.get("PSBA_BENCH_NO_SETTLE"):
+        run_steps(6 * args.segment)
     # warmup: W untimed LM iterations
     if args.warmup > 0:
         run_steps(args.warmup)

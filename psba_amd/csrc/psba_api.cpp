@@ -38,7 +38,9 @@ ProfScope::ProfScope(psba_ctx *hh, int kind) : h(hh) {
   if (h->spans_used == h->spans.size()) {
     psba_ctx::Span s;
     s.kind = kind;
-    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    if (hipEventCreateWithFlags(&s.a, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&s.b, hipEventDisableSystemFence) != hipSuccess)
+      return;
     h->spans.push_back(s);
   }
   idx = (int)h->spans_used++;
@@ -853,6 +855,18 @@ int psba_profile_enable(psba_handle h, int on) {
   CHECK_H(h);
   TRY(prof_flush(h));
   h->prof = on < 0 ? ~0u : (unsigned)on;  // negative: every class; otherwise a bit mask of classes
+  // event pairs are created here, not in front of the first profiled launches (hipEventCreate is
+  // not cheap, and those launches may be the ones being timed)
+  while (h->prof && h->spans.size() < 512) {
+    psba_ctx::Span s;
+    s.kind = 0;
+    // timing events only: without the system-scope fence a default event carries (it flushes
+    // caches between the kernels it sits between, and costs several microseconds itself)
+    if (hipEventCreateWithFlags(&s.a, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&s.b, hipEventDisableSystemFence) != hipSuccess)
+      break;
+    h->spans.push_back(s);
+  }
   return PSBA_OK;
 }
 
