@@ -97,6 +97,10 @@ int psba_residual(psba_handle h, int which, double *cost);
 int psba_linearize(psba_handle h, double coeff, double coeff_g);
 /* maxElmOfUV (PSBA/sba_func.h:58): max over diag(U), diag(V); global over ranks */
 int psba_max_diag(psba_handle h, double *out);
+/* The loop's prologue in one call and one synchronisation (PSBA/levmar.cpp:93-120): the cost at
+ * the current parameters, their linearization (as psba_linearize) and its largest diagonal
+ * entry.  The psba_linearize that follows with the same coefficients has nothing left to do. */
+int psba_begin(psba_handle h, double coeff, double coeff_g, double *cost, double *max_diag);
 /* update_UV + compute_Vinv + compute_Yblks + compute_S + compute_ea
  * (PSBA/sba_func.h:60-68,84-98,114-119; PSBA/levmar.cpp:126-131).  mu is applied on the
  * fly, U/V are not modified, so there is no restore_UVdiag.  Leaves this rank's

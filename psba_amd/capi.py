@@ -60,6 +60,7 @@ SIGNATURES = [
     ("psba_residual", C.c_int, [_h, C.c_int, _dp]),
     ("psba_linearize", C.c_int, [_h, C.c_double, C.c_double]),
     ("psba_max_diag", C.c_int, [_h, _dp]),
+    ("psba_begin", C.c_int, [_h, C.c_double, C.c_double, _dp, _dp]),
     ("psba_schur_assemble", C.c_int, [_h, C.c_double]),
     ("psba_schur_reduce", C.c_int, [_h]),
     ("psba_schur_solve", C.c_int, [_h]),
@@ -251,6 +252,12 @@ class Psba:
 
     def linearize(self, coeff=1.0, coeff_g=1.0):
         self._ck(lib.psba_linearize(self._h, coeff, coeff_g))
+
+    def begin(self, coeff=1.0, coeff_g=1.0):
+        """(cost, max diagonal) at the current parameters + their linearization, one sync."""
+        c, m = C.c_double(), C.c_double()
+        self._ck(lib.psba_begin(self._h, coeff, coeff_g, C.byref(c), C.byref(m)))
+        return c.value, m.value
 
     def max_diag(self):
         v = C.c_double()

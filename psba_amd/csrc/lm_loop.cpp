@@ -40,15 +40,15 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
   int flag = PSBA_ITER_CONTINUE;
   int itno = opts->start_itno;
 
-  LM_TRY(psba_residual(h, PSBA_PARAMS_CUR, &ex_L2));  // levmar.cpp:93-95
+  // levmar.cpp:93-95 and, of the first iteration, :103-108 and :114-120 -- one synchronisation
+  double maxdiag0 = 0;
+  LM_TRY(psba_begin(h, 1.0, 1.0, &ex_L2, &maxdiag0));
   res->init_err = ex_L2;
 
   for (; itno < opts->max_iter && flag == PSBA_ITER_CONTINUE; itno++) {  // :100
     LM_TRY(psba_linearize(h, 1.0, 1.0));                                  // :103-108
     if (first) {                                                          // :114-120
-      double maxdiag = 0;
-      LM_TRY(psba_max_diag(h, &maxdiag));
-      mu = tau * maxdiag;
+      mu = tau * maxdiag0;
       res->mu0 = mu;
       first = false;
       p_L2 = 1e+3;

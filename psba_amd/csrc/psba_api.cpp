@@ -366,13 +366,18 @@ static int fetch_scalars(psba_ctx *h) {
   return PSBA_OK;
 }
 
-int psba_residual(psba_handle h, int which, double *cost) {
-  CHECK_H(h);
-  NEED(h, h->uploaded, "no problem uploaded");
+static int enqueue_residual(psba_ctx *h, int which) {
   TRY(launch_residual(h, which, nullptr));
   if (h->comm)
     RCCL(h, ncclAllReduce(h->scal + SC_COST, h->scal + SC_COST, 1, ncclDouble, ncclSum, h->comm,
                           h->stream));
+  return PSBA_OK;
+}
+
+int psba_residual(psba_handle h, int which, double *cost) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  TRY(enqueue_residual(h, which));
   TRY(fetch_scalars(h));
   if (cost) *cost = h->h_scal[SC_COST];
   return PSBA_OK;
@@ -394,9 +399,7 @@ int psba_linearize(psba_handle h, double coeff, double coeff_g) {
   return PSBA_OK;
 }
 
-int psba_max_diag(psba_handle h, double *out) {
-  CHECK_H(h);
-  NEED(h, h->linearized, "psba_linearize first");
+static int enqueue_max_diag(psba_ctx *h) {
   if (h->comm) {
     // diag(U) is a sum over all points: reduce the per-rank U first (scratch copy in dp)
     double *tmp = h->dp;  // dp is free between linearize and the first solve
@@ -413,6 +416,31 @@ int psba_max_diag(psba_handle h, double *out) {
   } else {
     TRY(launch_max_diag(h));
   }
+  return PSBA_OK;
+}
+
+int psba_begin(psba_handle h, double coeff, double coeff_g, double *cost, double *max_diag) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  TRY(enqueue_residual(h, PSBA_PARAMS_CUR));
+  h->coeff = coeff;
+  h->coeff_g = coeff_g;
+  TRY(launch_linearize(h, false));
+  h->linearized = true;
+  h->assembled = h->solved = h->backsubbed = false;
+  h->ahead = false;
+  TRY(enqueue_max_diag(h));
+  TRY(fetch_scalars(h));
+  if (cost) *cost = h->h_scal[SC_COST];
+  if (max_diag) *max_diag = h->h_scal[SC_MAXDIAG];
+  h->lin_is_ahead = true;  // the next psba_linearize with these coefficients has nothing left to do
+  return PSBA_OK;
+}
+
+int psba_max_diag(psba_handle h, double *out) {
+  CHECK_H(h);
+  NEED(h, h->linearized, "psba_linearize first");
+  TRY(enqueue_max_diag(h));
   TRY(fetch_scalars(h));
   if (out) *out = h->h_scal[SC_MAXDIAG];
   return PSBA_OK;
