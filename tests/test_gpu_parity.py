@@ -510,3 +510,22 @@ def test_solve_residual_property(gpu, n_cams, n_pts):
     ref = np.linalg.solve(S, ea)
     np.testing.assert_allclose(dpa, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
     gpu.restore_UVdiag()
+
+
+def test_begin_equals_residual_linearize_max_diag(gpu, problems):
+    """psba_begin (one synchronisation) against the three verbs it stands for."""
+    prob = problems["54cams"]
+    gpu.upload_problem(prob)
+    cost = gpu.residual()
+    gpu.linearize(1.0, 1.0)
+    md = gpu.max_diag()
+    gpu.upload_problem(prob)
+    c2, m2 = gpu.begin(1.0, 1.0)
+    assert abs(c2 - cost) <= 1e-13 * cost  # one atomic per workgroup: summation order is not fixed
+    assert abs(m2 - md) <= 1e-13 * md  # U's LDS atomics: summation order is not fixed
+    gpu.linearize(1.0, 1.0)            # nothing to do: the linearization is already there
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    gpu.update_UV(mu)
+    close(gpu.compute_S(), o.schur(lin, mu)["S"], 1e-11, "S")
