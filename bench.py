@@ -127,7 +127,7 @@ def main():
         res = None
         while done < n:
             ts = time.perf_counter()
-            h.set_params(cams0, pts0)
+            h.reset_params()  # the uploaded (initial) parameters again, device side
             res, _ = h.levmar(max_iter=min(args.segment, n - done), tr_handoff=False, log_cap=0)
             if os.environ.get("PSBA_BENCH_DEBUG"):
                 print(f"[bench] segment of {res.iters}: {1e6 * (time.perf_counter() - ts):.1f} us", file=sys.stderr)

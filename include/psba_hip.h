@@ -78,6 +78,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
                         const double *pts3D, const int *iidx, const int *jidx);
 /* overwrite the current parameters (cams[nCams*6], pts[n3Dpts*3]) */
 int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D);
+/* back to the parameters given to psba_upload_problem (device-side copy, no synchronisation):
+ * what a driver that reruns the loop from the same start, like bench.py, would otherwise do
+ * with psba_set_params */
+int psba_reset_params(psba_handle h);
 /* read back the current (PSBA_PARAMS_CUR) or proposed (PSBA_PARAMS_NEW) parameters */
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);

@@ -55,6 +55,7 @@ SIGNATURES = [
     ("psba_version", C.c_char_p, []),
     ("psba_upload_problem", C.c_int, [_h, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     ("psba_set_params", C.c_int, [_h, _dp, _dp]),
+    ("psba_reset_params", C.c_int, [_h]),
     ("psba_get_params", C.c_int, [_h, C.c_int, _dp, _dp]),
     ("psba_get_dims", C.c_int, [_h, _ip, _ip, _ip]),
     ("psba_residual", C.c_int, [_h, C.c_int, _dp]),
@@ -238,6 +239,9 @@ class Psba:
     def set_params(self, cams, pts):
         c, p = _c(cams).reshape(-1), _c(pts).reshape(-1)
         self._ck(lib.psba_set_params(self._h, _d(c), _d(p)))
+
+    def reset_params(self):
+        self._ck(lib.psba_reset_params(self._h))
 
     def get_params(self, which=PARAMS_CUR):
         c, p = np.empty(self.nA), np.empty(self.nB)

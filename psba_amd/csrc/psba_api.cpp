@@ -99,6 +99,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->iidx);
   dev_free(h->jidx);
   dev_free(h->ptr);
+  dev_free(h->params0);
   dev_free(h->tile_pt);
   dev_free(h->tile_desc);
   dev_free(h->W);
@@ -258,6 +259,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->cams[1], (size_t)d.nA));
   TRY(dev_alloc(h, &h->pts[0], (size_t)d.nB));
   TRY(dev_alloc(h, &h->pts[1], (size_t)d.nB));
+  TRY(dev_alloc(h, &h->params0, (size_t)d.nT));
   TRY(dev_alloc(h, &h->impts, (size_t)2 * d.nO));
   TRY(dev_alloc(h, &h->iidx, (size_t)d.nO));
   TRY(dev_alloc(h, &h->jidx, (size_t)d.nO));
@@ -315,6 +317,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, H2D(h->camconst, cc.data(), sizeof(double) * cc.size()));
   PSBA_HIP(h, H2D(h->cams[0], camsEx, sizeof(double) * d.nA));
   PSBA_HIP(h, H2D(h->pts[0], pts3D, sizeof(double) * d.nB));
+  PSBA_HIP(h, H2D(h->params0, camsEx, sizeof(double) * d.nA));
+  PSBA_HIP(h, H2D(h->params0 + d.nA, pts3D, sizeof(double) * d.nB));
   PSBA_HIP(h, H2D(h->impts, impts, sizeof(double) * 2 * (size_t)d.nO));
   PSBA_HIP(h, H2D(h->iidx, iidx, sizeof(int) * (size_t)d.nO));
   PSBA_HIP(h, H2D(h->jidx, jidx, sizeof(int) * (size_t)d.nO));
@@ -338,6 +342,18 @@ int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D) {
   PSBA_HIP(h, hipMemcpyAsync(h->pts[h->cur], pts3D, sizeof(double) * h->d.nB,
                              hipMemcpyHostToDevice, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  h->linearized = h->assembled = h->solved = h->backsubbed = false;
+  h->ahead = h->lin_is_ahead = h->backsub_pending = false;
+  return PSBA_OK;
+}
+
+int psba_reset_params(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  PSBA_HIP(h, hipMemcpyAsync(h->cams[h->cur], h->params0, sizeof(double) * h->d.nA, hipMemcpyDeviceToDevice,
+                             h->stream));
+  PSBA_HIP(h, hipMemcpyAsync(h->pts[h->cur], h->params0 + h->d.nA, sizeof(double) * h->d.nB,
+                             hipMemcpyDeviceToDevice, h->stream));
   h->linearized = h->assembled = h->solved = h->backsubbed = false;
   h->ahead = h->lin_is_ahead = h->backsub_pending = false;
   return PSBA_OK;

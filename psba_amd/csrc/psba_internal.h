@@ -72,6 +72,7 @@ struct psba_ctx {
   double *camconst = nullptr;   // [nC][9]  K5 | q0(4)               (Kparas_buffer, initcams_buffer)
   double *cams[2] = {nullptr, nullptr};  // [nC][6] cur / proposed   (cams_buffer, newCams_buffer)
   double *pts[2] = {nullptr, nullptr};   // [nP][3] cur / proposed   (pts3D_buffer, newPts3D_buffer)
+  double *params0 = nullptr;    // [nT] the parameters as uploaded (psba_reset_params)
   double *impts = nullptr;      // [nO][2]                           (impts_buffer)
   int *iidx = nullptr;          // [nO] point of each observation    (iidx_buffer)
   int *jidx = nullptr;          // [nO] camera of each observation   (jidx_buffer)

@@ -529,3 +529,17 @@ def test_begin_equals_residual_linearize_max_diag(gpu, problems):
     mu = 1e-3 * lin["maxdiag"]
     gpu.update_UV(mu)
     close(gpu.compute_S(), o.schur(lin, mu)["S"], 1e-11, "S")
+
+
+def test_reset_params_restores_the_uploaded_parameters(gpu, problems):
+    prob = problems["7cams"]
+    gpu.upload_problem(prob)
+    res1, _ = gpu.levmar(max_iter=4, tr_handoff=False)
+    c, p = gpu.get_params()
+    assert np.abs(c - np.asarray(prob["cams"]).reshape(c.shape)).max() > 0
+    gpu.reset_params()
+    c, p = gpu.get_params()
+    np.testing.assert_array_equal(c, np.asarray(prob["cams"]).reshape(c.shape))
+    np.testing.assert_array_equal(p, np.asarray(prob["pts"]).reshape(p.shape))
+    res2, _ = gpu.levmar(max_iter=4, tr_handoff=False)
+    assert abs(res2.final_err - res1.final_err) <= 1e-12 * res1.final_err
