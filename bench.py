@@ -114,7 +114,6 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
     h.upload_problem(prob)
-    cams0, pts0 = np.array(prob["cams"], copy=True), np.array(prob["pts"], copy=True)
 
     def barrier():
         if dist is not None:
