@@ -136,18 +136,32 @@ def main():
             tries += res.tries
         return done, tries, res
 
-    # device wake-up, before the W warm-up steps: the first ~6 ms of sustained load on a fresh
-    # process run at a lower clock and end in a ~0.8 ms stall when the clock steps up (seen as one
-    # slow segment, then ~3 % faster ones: PSBA_BENCH_DEBUG=1 prints the segment times).  Sixty
-    # untimed LM iterations put that transition behind us whatever W and K are.
+    # HIP events on the graded kernel only during the timed region (every timed launch costs two
+    # event records on the stream); the other kernel classes are timed in an extra pass afterwards.
+    # Enabled before anything runs, so that the event pool is created AND used before the timing
+    # starts (growing the runtime's signal pool has been seen to stall the stream for ~0.8 ms).
+    h.profile_enable(int(os.environ.get("PSBA_BENCH_PROF_MASK", 1 << capi.K_SCHUR)))
+    # device wake-up, before the W warm-up steps: a fresh process (more so on a fresh box) runs
+    # its first milliseconds of sustained load at a lower clock and has been seen to stall ~0.8 ms
+    # once or twice early on (PSBA_BENCH_DEBUG=1 prints the segment times).  Untimed segments are
+    # run until three in a row agree to 2 % (at least 12, at most 60: 25-120 ms), which puts that
+    # behind us whatever W and K are.
     if not os.environ.get("PSBA_BENCH_NO_SETTLE"):
-        run_steps(6 * args.segment)
+        times = []
+        while len(times) < 60:
+            ts = time.perf_counter()
+            run_steps(args.segment)
+            times.append(time.perf_counter() - ts)
+            if dist is not None:  # every rank must take the same number of segments
+                import torch
+                t = torch.tensor([times[-1]], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                times[-1] = float(t[0])
+            if len(times) >= 12 and max(times[-3:]) <= 1.02 * min(times[-3:]):
+                break
     # warmup: W untimed LM iterations
     if args.warmup > 0:
         run_steps(args.warmup)
-    # HIP events on the graded kernel only during the timed region (every timed launch costs two
-    # event records on the stream); the other kernel classes are timed in an extra pass afterwards
-    h.profile_enable(int(os.environ.get("PSBA_BENCH_PROF_MASK", 1 << capi.K_SCHUR)))
     h.profile_reset()
     barrier()
     t0 = time.perf_counter()
