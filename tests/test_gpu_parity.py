@@ -543,3 +543,38 @@ def test_reset_params_restores_the_uploaded_parameters(gpu, problems):
     np.testing.assert_array_equal(p, np.asarray(prob["pts"]).reshape(p.shape))
     res2, _ = gpu.levmar(max_iter=4, tr_handoff=False)
     assert abs(res2.final_err - res1.final_err) <= 1e-12 * res1.final_err
+
+
+@pytest.mark.parametrize("n_cams,n_pts,mean_track,min_track,max_track", [
+    (8, 500, 7.5, 2, 8),      # every point seen by almost every camera
+    (52, 800, 30.0, 20, 52),  # long tracks: up to 1378 products per point
+    (17, 1200, 2.2, 1, 5),    # short tracks, single observations
+    (64, 600, 10.0, 3, 64),
+    (33, 5000, 3.0, 2, 12),
+    (120, 1500, 6.0, 2, 30),  # two-kernel panels, 25+ camera-row groups
+])
+def test_problem_shape_sweep(gpu, n_cams, n_pts, mean_track, min_track, max_track):
+    """The whole path against the oracle over problem shapes that stress different parts of the
+    static K2 schedule (track length distribution, number of groups) and of the panel chain."""
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=n_cams, n_pts=n_pts, mean_track=mean_track, seed=100 + n_cams,
+                              min_track=min_track, max_track=max_track)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    gpu.linearize(1.0, 1.0)
+    gpu.update_UV(mu)
+    close(gpu.compute_S(), sch["S"], 1e-11, "S")
+    close(gpu.compute_ea(), sch["eab"][: o.nA], 1e-10, "ea")
+    ret, dp, _ = o.solve(lin, sch)
+    rc, dpa = gpu.SPDinv_matVec()
+    assert rc == 0 and ret == 0.0
+    close(dpa, dp[: o.nA], 1e-8, "dpa")
+    close(gpu.compute_dpb(), dp, 1e-8, "dp")
+    gpu.restore_UVdiag()
+    gpu.upload_problem(prob)
+    res, _ = gpu.levmar(max_iter=5, tr_handoff=False)
+    ores, _ = Oracle(prob).levmar(max_iter=5, tr_handoff=False)
+    assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
