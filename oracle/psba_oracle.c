@@ -18,6 +18,28 @@
 #define PNP 3
 #define MNP 2
 
+/* ORC_OMP (oracle/Makefile: libpsba_oracle_omp.so) adds OpenMP to the loops for the all-core CPU
+ * baseline of bench.py.  The serial library, which is what every test and pin uses, is compiled
+ * without it and is unchanged: its sums run in the reference's order.  The OpenMP build keeps
+ * that order inside a point and gives up only the order of the per-camera / per-block sums. */
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_DO_PRAGMA(x) _Pragma(#x)
+#define ORC_PAR_FOR ORC_DO_PRAGMA(omp parallel for schedule(static))
+#define ORC_PAR_FOR_RED(...) ORC_DO_PRAGMA(omp parallel for schedule(static) reduction(__VA_ARGS__))
+#else
+#define ORC_PAR_FOR
+#define ORC_PAR_FOR_RED(...)
+#endif
+
+int orc_threads(void) {
+#ifdef ORC_OMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -36,6 +58,19 @@ static void *xmalloc(size_t n) {
 /* ---- camera model --------------------------------------------------------------------
  * q_l = (sqrt(1-|v|^2), v); q = q_l (x) q0 (Hamilton, local rotation on the left),
  * CL_files/compute_exQT.cl:36-49.  q = (q[0]; q[1..3]) scalar first. */
+#ifdef ORC_OMP
+/* first observation of every point (observations are point-major) */
+static int *point_starts(int nP, int nO, const int *iidx) {
+  int *ps = (int *)xmalloc(sizeof(int) * ((size_t)nP + 1));
+  int a = 0;
+  for (int i = 0; i <= nP; i++) {
+    while (a < nO && iidx[a] < i) a++;
+    ps[i] = a;
+  }
+  return ps;
+}
+#endif
+
 static void compose_quat(const double *q0, const double *v, double *q) {
   double si = sqrt(1 - v[0] * v[0] - v[1] * v[1] - v[2] * v[2]);
   double s0 = q0[0], a1 = q0[1], a2 = q0[2], a3 = q0[3];
@@ -76,6 +111,7 @@ static void project(const double *K, const double *P, double *xy) {
 void orc_compute_exQT(int nO, const double *K, const double *impts, const double *initrot,
                       const double *cams, const double *pts, const int *iidx, const int *jidx,
                       double *ex) {
+  ORC_PAR_FOR
   for (int idx = 0; idx < nO; idx++) {
     int i = iidx[idx], j = jidx[idx];
     double q[4], P[3], xy[2];
@@ -91,6 +127,7 @@ void orc_compute_exQT(int nO, const double *K, const double *impts, const double
 void orc_compute_jacobiQT(int nO, const double *K, const double *initrot, const double *cams,
                           const double *pts, const int *iidx, const int *jidx, double *JA,
                           double *JB) {
+  ORC_PAR_FOR
   for (int idx = 0; idx < nO; idx++) {
     int i = iidx[idx], j = jidx[idx];
     const double *Kj = K + 5 * j, *q0 = initrot + 4 * j, *v = cams + 6 * j, *M = pts + 3 * i;
@@ -157,6 +194,7 @@ void orc_compute_U(int nC, int nO, const double *JA, const int *jidx, double coe
   memset(U, 0, sizeof(double) * 36 * (size_t)nC);
   /* observations are visited in point-ascending order, so each U_j(r,c) is summed over i
    * ascending exactly as compute_U.cl:22-29 does */
+  ORC_PAR_FOR_RED(+ : U[0 : 36 * nC])
   for (int idx = 0; idx < nO; idx++) {
     const double *A = JA + 12 * idx;
     double *Uj = U + 36 * jidx[idx];
@@ -175,12 +213,25 @@ void orc_compute_U(int nC, int nO, const double *JA, const int *jidx, double coe
 void orc_compute_V(int nC, int nP, int nO, const double *JB, const int *iidx, double coeff,
                    double *V, double *UVdiag) {
   memset(V, 0, sizeof(double) * 9 * (size_t)nP);
+#ifdef ORC_OMP
+  int *ps = point_starts(nP, nO, iidx);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nP; i++)
+    for (int idx = ps[i]; idx < ps[i + 1]; idx++) {
+      const double *B = JB + 6 * idx;
+      double *Vi = V + 9 * i;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Vi[3 * r + c] = Vi[3 * r + c] + B[r] * B[c] + B[3 + r] * B[3 + c];
+    }
+  free(ps);
+#else
   for (int idx = 0; idx < nO; idx++) {
     const double *B = JB + 6 * idx;
     double *Vi = V + 9 * iidx[idx];
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) Vi[3 * r + c] = Vi[3 * r + c] + B[r] * B[c] + B[3 + r] * B[3 + c];
   }
+#endif
   for (int i = 0; i < nP; i++)
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) {
@@ -191,6 +242,7 @@ void orc_compute_V(int nC, int nP, int nO, const double *JB, const int *iidx, do
 }
 
 void orc_compute_Wblks(int nO, const double *JA, const double *JB, double coeff, double *W) {
+  ORC_PAR_FOR
   for (int idx = 0; idx < nO; idx++) {
     const double *A = JA + 12 * idx, *B = JB + 6 * idx;
     for (int r = 0; r < 6; r++)
@@ -202,6 +254,25 @@ void orc_compute_g(int nC, int nP, int nO, double coeff, const double *JA, const
                    const int *iidx, const int *jidx, const double *ex, double *g) {
   int nA = 6 * nC, nT = 6 * nC + 3 * nP;
   memset(g, 0, sizeof(double) * (size_t)nT);
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(static) reduction(+ : g[0 : nA])
+  for (int idx = 0; idx < nO; idx++) {
+    const double *A = JA + 12 * idx;
+    double e0 = ex[2 * idx], e1 = ex[2 * idx + 1];
+    double *ga = g + 6 * jidx[idx];
+    for (int k = 0; k < 6; k++) ga[k] = ga[k] + A[k] * e0 + A[6 + k] * e1;
+  }
+  int *ps = point_starts(nP, nO, iidx);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nP; i++)
+    for (int idx = ps[i]; idx < ps[i + 1]; idx++) {
+      const double *B = JB + 6 * idx;
+      double e0 = ex[2 * idx], e1 = ex[2 * idx + 1];
+      double *gb = g + nA + 3 * i;
+      for (int k = 0; k < 3; k++) gb[k] = gb[k] + B[k] * e0 + B[3 + k] * e1;
+    }
+  free(ps);
+#else
   for (int idx = 0; idx < nO; idx++) {
     const double *A = JA + 12 * idx, *B = JB + 6 * idx;
     double e0 = ex[2 * idx], e1 = ex[2 * idx + 1];
@@ -209,6 +280,7 @@ void orc_compute_g(int nC, int nP, int nO, double coeff, const double *JA, const
     for (int k = 0; k < 6; k++) ga[k] = ga[k] + A[k] * e0 + A[6 + k] * e1;
     for (int k = 0; k < 3; k++) gb[k] = gb[k] + B[k] * e0 + B[3 + k] * e1;
   }
+#endif
   for (int t = 0; t < nT; t++) g[t] = coeff * g[t];
 }
 
@@ -235,6 +307,7 @@ void orc_restore_UVdiag(int nC, int nP, double *U, double *V, const double *UVdi
 
 double orc_compute_Vinv(int nP, const double *V, double *Vinv) {
   double ret = 0.0;
+  ORC_PAR_FOR_RED(max : ret)
   for (int i = 0; i < nP; i++) {
     const double *a = V + 9 * i;
     double a11 = a[0], a12 = a[1], a13 = a[2], a22 = a[4], a23 = a[5], a33 = a[8];
@@ -257,6 +330,7 @@ double orc_compute_Vinv(int nP, const double *V, double *Vinv) {
 }
 
 void orc_compute_Yblks(int nO, const int *iidx, const double *W, const double *Vinv, double *Y) {
+  ORC_PAR_FOR
   for (int idx = 0; idx < nO; idx++) {
     const double *Vi = Vinv + 9 * iidx[idx];
     for (int r = 0; r < 6; r++) {
@@ -271,7 +345,26 @@ void orc_compute_S(int nC, int nP, int nO, const int *iidx, const int *jidx, con
   int nA = 6 * nC;
   (void)nP;
   memset(S, 0, sizeof(double) * (size_t)nA * nA);
+#ifdef ORC_OMP
+  {
+    int *ps = point_starts(nP, nO, iidx);
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : S[0 : nA * nA])
+    for (int i = 0; i < nP; i++)
+      for (int a = ps[i]; a < ps[i + 1]; a++)
+        for (int b = ps[i]; b < ps[i + 1]; b++) {
+          int k = jidx[a], l = jidx[b];
+          for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++) {
+              const double *y = Y + 18 * a + 3 * r, *w = W + 18 * b + 3 * c;
+              S[(size_t)(6 * k + r) * nA + 6 * l + c] += y[0] * w[0] + y[1] * w[1] + y[2] * w[2];
+            }
+        }
+    free(ps);
+  }
+  int a0 = nO;
+#else
   int a0 = 0;
+#endif
   while (a0 < nO) {
     int a1 = a0;
     while (a1 < nO && iidx[a1] == iidx[a0]) a1++;
@@ -301,6 +394,7 @@ void orc_compute_ea(int nC, int nP, int nO, const int *iidx, const int *jidx, co
   (void)nP;
   double *sum = (double *)xmalloc(sizeof(double) * (size_t)nA);
   memset(sum, 0, sizeof(double) * (size_t)nA);
+  ORC_PAR_FOR_RED(+ : sum[0 : nA])
   for (int idx = 0; idx < nO; idx++) {
     const double *gb = g + nA + 3 * iidx[idx];
     for (int r = 0; r < 6; r++) {
@@ -320,13 +414,16 @@ double orc_chol_solve(int n, double *S, const double *ea, double *dpa) {
     double l = sqrt(d);
     if (!(d > 0.0) || !isfinite(l)) return 1.0;
     S[(size_t)j * n + j] = l;
+    int bad = 0;
+    ORC_PAR_FOR_RED(| : bad)
     for (int i = j + 1; i < n; i++) {
       double t = S[(size_t)i * n + j];
       for (int k = 0; k < j; k++) t -= S[(size_t)i * n + k] * S[(size_t)j * n + k];
       t = t / l;
-      if (!isfinite(t)) return 1.0;
+      if (!isfinite(t)) bad |= 1;
       S[(size_t)i * n + j] = t;
     }
+    if (bad) return 1.0;
   }
   for (int i = 0; i < n; i++) {
     double t = ea[i];
@@ -348,18 +445,32 @@ void orc_compute_eb(int nC, int nP, int nO, const int *iidx, const int *jidx, co
   int nA = 6 * nC;
   double *sum = (double *)xmalloc(sizeof(double) * 3 * (size_t)nP);
   memset(sum, 0, sizeof(double) * 3 * (size_t)nP);
+#ifdef ORC_OMP
+  int *ps = point_starts(nP, nO, iidx);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nP; i++)
+    for (int idx = ps[i]; idx < ps[i + 1]; idx++) {
+      const double *w = W + 18 * idx, *dpa = dp + 6 * jidx[idx];
+      double *s = sum + 3 * i;
+      for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 6; k++) s[c] = s[c] + w[3 * k + c] * dpa[k];
+    }
+  free(ps);
+#else
   for (int idx = 0; idx < nO; idx++) {
     const double *w = W + 18 * idx, *dpa = dp + 6 * jidx[idx];
     double *s = sum + 3 * iidx[idx];
     for (int c = 0; c < 3; c++)
       for (int k = 0; k < 6; k++) s[c] = s[c] + w[3 * k + c] * dpa[k];
   }
+#endif
   for (int t = 0; t < 3 * nP; t++) eab[nA + t] = g[nA + t] - sum[t];
   free(sum);
 }
 
 void orc_compute_dpb(int nC, int nP, const double *Vinv, const double *eab, double *dp) {
   int nA = 6 * nC;
+  ORC_PAR_FOR
   for (int i = 0; i < nP; i++) {
     const double *Vi = Vinv + 9 * i, *eb = eab + nA + 3 * i;
     for (int r = 0; r < 3; r++) dp[nA + 3 * i + r] = Vi[3 * r] * eb[0] + Vi[3 * r + 1] * eb[1] + Vi[3 * r + 2] * eb[2];
@@ -369,11 +480,13 @@ void orc_compute_dpb(int nC, int nP, const double *Vinv, const double *eab, doub
 void orc_compute_newp(int nA, int nB, const double *cams, const double *pts, const double *dp,
                       double *newcams, double *newpts) {
   for (int t = 0; t < nA; t++) newcams[t] = cams[t] + dp[t];
+  ORC_PAR_FOR
   for (int t = 0; t < nB; t++) newpts[t] = pts[t] + dp[nA + t];
 }
 
 double orc_L2_sq(int n, const double *x) {
   double sum = 0;
+  ORC_PAR_FOR_RED(+ : sum)
   for (int i = 0; i < n; i++) sum += x[i] * x[i];
   return sum;
 }

@@ -109,6 +109,10 @@ typedef struct {
 
 /* PSBA/levmar.cpp:45-256.  cams/pts are updated in place.  log rows are
  * (itno, new_err, rho, mu, accepted) one per completed damping try. */
+/* threads the library runs its loops on: 1, or omp_get_max_threads() in the OpenMP build
+ * (libpsba_oracle_omp.so, bench.py's all-core CPU baseline only) */
+int orc_threads(void);
+
 int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
                const double *initrot, double *cams, double *pts, const int *iidx,
                const int *jidx, const orc_lm_opts *opts, orc_lm_result *res, double *log);

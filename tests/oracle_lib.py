@@ -134,3 +134,34 @@ class Oracle:
         _lm(self.nC, self.nP, self.nO, self.K, self.impts, self.initrot, self.cams, self.pts, self.iidx,
             self.jidx, C.byref(opts), C.byref(res), log.ctypes.data_as(C.c_void_p))
         return res, log[: res.n_log].copy()
+
+
+_SO_OMP = os.path.join(_ROOT, "oracle", "libpsba_oracle_omp.so")
+
+
+def levmar_all_cores(prob, max_iter=10, tr_handoff=False):
+    """orc_levmar of the OpenMP build of the same source (oracle/Makefile): only for bench.py's
+    all-core CPU baseline -- no test or pin uses it.  Returns (result, threads used)."""
+    src = os.path.join(_ROOT, "oracle", "psba_oracle.c")
+    if (not os.path.exists(_SO_OMP)) or os.path.getmtime(_SO_OMP) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    # as many threads as this process may really use: the affinity mask, capped at the CPU share of
+    # a one-GPU box (16) -- an OpenMP team larger than the CPUs it gets spins on its barriers
+    # (seen: minutes instead of seconds), hence also the passive wait policy
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(n, 16))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("OMP_DYNAMIC", "FALSE")
+    lib = C.CDLL(_SO_OMP)
+    f = lib.orc_levmar
+    f.restype = _lm.restype
+    f.argtypes = _lm.argtypes
+    lib.orc_threads.restype = C.c_int
+    o = Oracle(prob)
+    opts = LmOpts(max_iter, int(tr_handoff), 0, 0)
+    res = LmResult()
+    log = np.zeros((1, 5))
+    f(o.nC, o.nP, o.nO, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, C.byref(opts), C.byref(res),
+      log.ctypes.data_as(C.c_void_p))
+    return res, int(lib.orc_threads())
+

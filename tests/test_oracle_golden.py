@@ -112,3 +112,14 @@ def test_chol_solve_flags_indefinite_matrix():
     S = np.array([[1.0, 2.0], [2.0, 1.0]]).reshape(-1).copy()
     x = np.zeros(2)
     assert _chol(2, S, np.ones(2), x) == 1.0
+
+
+def test_openmp_build_of_the_oracle_agrees_with_the_serial_one(problems):
+    """libpsba_oracle_omp.so (bench.py's all-core CPU baseline) is the same source with OpenMP:
+    per-camera / per-block sums lose the reference's order, nothing else changes."""
+    from oracle_lib import Oracle, levmar_all_cores
+    prob = problems["54cams"]
+    ser, _ = Oracle(prob).levmar(max_iter=6, tr_handoff=False, log_cap=0)
+    par, threads = levmar_all_cores(prob, max_iter=6)
+    assert threads >= 1 and par.iters == ser.iters
+    assert abs(par.final_err - ser.final_err) <= 1e-11 * ser.final_err
