@@ -124,6 +124,61 @@ void orc_compute_exQT(int nO, const double *K, const double *impts, const double
   }
 }
 
+/* The reference's host-side twin of the residual, PSBA/levmar_func_cpu.cpp:82-140 (compute_proj_err)
+ * with its helpers :147-178 (quatMultFast) and :185-223 (calcImgProjFullR).  Same mathematics as
+ * orc_compute_exQT, different arithmetic: the quaternion product is the eight-multiplication
+ * scheme (products of sums and differences of the components), the rotation is the explicit
+ * sandwich q (0,M) q* expanded component by component, the division is a reciprocal followed
+ * by products, and ONE intrinsics vector K[0..4] serves every camera (:104-113 passes the base
+ * pointer).  The golden value of SURVEY.md 8(c) / Appendix A.5 for this path differs from the
+ * kernel path in the 14th digit, which is what tests/test_oracle_golden.py pins. */
+static void quat_mul_8(const double *a, const double *b, double *p) {
+  /* levmar_func_cpu.cpp:152-177 */
+  double s1 = (a[0] + a[1]) * (b[0] + b[1]);
+  double s2 = (a[3] - a[2]) * (b[2] - b[3]);
+  double s3 = (a[1] - a[0]) * (b[2] + b[3]);
+  double s4 = (a[2] + a[3]) * (b[1] - b[0]);
+  double s5 = (a[1] + a[3]) * (b[1] + b[2]);
+  double s6 = (a[1] - a[3]) * (b[1] - b[2]);
+  double s7 = (a[0] + a[2]) * (b[0] - b[3]);
+  double s8 = (a[0] - a[2]) * (b[0] + b[3]);
+  double h = 0.5 * (s5 - s6 + s7 + s8);
+  p[0] = s2 + h - s5;
+  p[1] = s1 - h - s6;
+  p[2] = -s3 + h - s8;
+  p[3] = -s4 + h - s7;
+}
+
+void orc_compute_proj_err_twin(int nO, int nC, const double *K, const double *impts,
+                               const double *initrot, const double *cams, const double *pts,
+                               const int *iidx, const int *jidx, double *ex) {
+  (void)nC;
+  for (int idx = 0; idx < nO; idx++) {
+    int i = iidx[idx], j = jidx[idx];
+    const double *v = cams + 6 * j, *t = v + 3, *M = pts + 3 * i;
+    double ql[4], q[4];
+    ql[0] = sqrt(1 - v[0] * v[0] - v[1] * v[1] - v[2] * v[2]); /* :107 */
+    ql[1] = v[0];
+    ql[2] = v[1];
+    ql[3] = v[2];
+    quat_mul_8(ql, initrot + 4 * j, q); /* :111 */
+    /* q (0,M): scalar part, then vector part (:204-208) */
+    double ps = -M[0] * q[1] - q[2] * M[1] - q[3] * M[2];
+    double px = q[0] * M[0] + q[2] * M[2] - q[3] * M[1];
+    double py = M[1] * q[0] + q[3] * M[0] - M[2] * q[1];
+    double pz = q[0] * M[2] + M[1] * q[1] - q[2] * M[0];
+    /* (q (0,M)) q*, vector part, plus t (:209-213) */
+    double X = -q[1] * ps + q[0] * px - py * q[3] + q[2] * pz + t[0];
+    double Y = -q[2] * ps + q[0] * py - pz * q[1] + q[3] * px + t[1];
+    double Z = -ps * q[3] + q[0] * pz - q[2] * px + q[1] * py + t[2];
+    double inv = 1 / Z;
+    double x = (K[0] * X + K[4] * Y + K[1] * Z) * inv;
+    double y = (K[0] * K[3] * Y + K[2] * Z) * inv;
+    ex[2 * idx] = impts[2 * idx] - x;         /* :114-115 */
+    ex[2 * idx + 1] = impts[2 * idx + 1] - y;
+  }
+}
+
 void orc_compute_jacobiQT(int nO, const double *K, const double *initrot, const double *cams,
                           const double *pts, const int *iidx, const int *jidx, double *JA,
                           double *JB) {

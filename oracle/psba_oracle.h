@@ -37,6 +37,13 @@ void orc_compute_exQT(int nO, const double *K, const double *impts, const double
                       const double *cams, const double *pts, const int *iidx, const int *jidx,
                       double *ex);
 
+/* PSBA/levmar_func_cpu.cpp:82-140 with :147-178 and :185-223: the reference's CPU twin of the
+ * residual in its own arithmetic (eight-multiplication quaternion product, expanded sandwich
+ * rotation, reciprocal); K is ONE intrinsics vector shared by all cameras. */
+void orc_compute_proj_err_twin(int nO, int nC, const double *K, const double *impts,
+                               const double *initrot, const double *cams, const double *pts,
+                               const int *iidx, const int *jidx, double *ex);
+
 /* CL_files/compute_jacobiQT.cl:7-141 ; PSBA/levmar_func_cpu.cpp:28-49,227-455.
  * Own analytic derivation from the projection model, not the
  * Maple-generated expression list. */

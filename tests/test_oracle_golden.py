@@ -123,3 +123,43 @@ def test_openmp_build_of_the_oracle_agrees_with_the_serial_one(problems):
     par, threads = levmar_all_cores(prob, max_iter=6)
     assert threads >= 1 and par.iters == ser.iters
     assert abs(par.final_err - ser.final_err) <= 1e-11 * ser.final_err
+
+
+def test_cpu_twin_residual_matches_its_golden(golden, problems):
+    """PSBA/levmar_func_cpu.cpp:82-140 (compute_proj_err, the CPU path the north star names) in
+    its own arithmetic (eight-multiplication quaternion product, expanded sandwich rotation,
+    reciprocal, one shared K), summed as PSBA/misc.cpp:151-157 does: all 16 printed digits of
+    the golden of SURVEY.md 8(c) / Appendix A.5.  The kernel-path value differs from it in the
+    14th digit, so this pins the twin's arithmetic, not just the model."""
+    import ctypes as C
+    from oracle_lib import _dp, _ip, _lib
+    o = Oracle(problems["7cams"])
+    f = _lib.orc_compute_proj_err_twin
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
+    l2 = _lib.orc_L2_sq
+    l2.restype = C.c_double
+    l2.argtypes = [C.c_int, _dp]
+    ex = np.empty(2 * o.nO)
+    f(o.nO, o.nC, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, ex)
+    twin = l2(2 * o.nO, ex)
+    assert rel(twin, golden["init_err_7cams_cpu_twin"]) < 2e-16
+    # and the two paths agree per observation to rounding
+    np.testing.assert_allclose(ex, o.exQT(), rtol=0, atol=1e-11)
+    kern = l2(2 * o.nO, o.exQT())
+    assert 0 < rel(kern, twin) < 1e-13
+
+
+@pytest.mark.parametrize("cams,pts", [("3cams", "3pts"), ("5cams", "5pts"), ("9cams", "9pts"),
+                                      ("9camsvarK", "9pts"), ("54camsvarK", "54pts")])
+def test_lm_on_the_other_bundled_sets(cams, pts):
+    """The bundled problems the survey holds no goldens for: the oracle's LM must at least
+    decrease the cost monotonically over accepted steps and end in a regular stop."""
+    import os
+    from conftest import DATA
+    from sba_text import read_problem
+    prob = read_problem(os.path.join(DATA, cams + ".txt"), os.path.join(DATA, pts + ".txt"))
+    res, log = Oracle(prob).levmar(max_iter=50, tr_handoff=False)
+    acc = log[log[:, 4] > 0]
+    assert np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
+    assert res.flag in (3, 5, 6) and res.final_err < res.init_err
