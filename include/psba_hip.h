@@ -85,6 +85,11 @@ int psba_reset_params(psba_handle h);
 /* read back the current (PSBA_PARAMS_CUR) or proposed (PSBA_PARAMS_NEW) parameters */
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
+/* which S-assembly route the uploaded problem takes: 0 = LDS-resident partitions of the block
+ * triangle with the static schedule (camera counts up to a few hundred), 1 = global fp64 atomics
+ * straight into S (more cameras than 64 LDS-sized camera-row groups can hold).  The reference has
+ * one route for every size (CL_files/compute_S.cl:6-78). */
+int psba_schur_path(psba_handle h, int *path);
 
 /* ---- fused verbs (what the optimiser loops call) --------------------------------------
  * One damping try = psba_schur_assemble -> psba_schur_reduce -> psba_schur_solve ->

@@ -58,6 +58,7 @@ SIGNATURES = [
     ("psba_reset_params", C.c_int, [_h]),
     ("psba_get_params", C.c_int, [_h, C.c_int, _dp, _dp]),
     ("psba_get_dims", C.c_int, [_h, _ip, _ip, _ip]),
+    ("psba_schur_path", C.c_int, [_h, C.POINTER(C.c_int)]),
     ("psba_residual", C.c_int, [_h, C.c_int, _dp]),
     ("psba_linearize", C.c_int, [_h, C.c_double, C.c_double]),
     ("psba_max_diag", C.c_int, [_h, _dp]),
@@ -249,6 +250,12 @@ class Psba:
         return c.reshape(self.nC, 6), p.reshape(self.nP, 3)
 
     # ---- fused verbs ----
+    def schur_path(self):
+        """0: LDS-partition schedule, 1: global-atomic assembly kernel (psba_schur_path)."""
+        v = C.c_int()
+        self._ck(lib.psba_schur_path(self._h, C.byref(v)))
+        return v.value
+
     def residual(self, which=PARAMS_CUR):
         v = C.c_double()
         self._ck(lib.psba_residual(self._h, which, C.byref(v)))

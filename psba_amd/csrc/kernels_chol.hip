@@ -353,8 +353,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double *Lw, double 
   if (bad) status[1] = try_id;
 }
 
-static bool g_chol_attr = false;
-
 int launch_chol_solve(psba_ctx *h) {
   // default: the panel chain on the whole chip (kernels_chol_graph.hip); PSBA_CHOL_SINGLE=1
   // selects this file's single-workgroup kernel
@@ -366,11 +364,11 @@ int launch_chol_solve(psba_ctx *h) {
   if (nTiles > 4 * CHOL_WAVES || 16 * nTiles > CHOL_THREADS + CB || n32 > CHOL_THREADS ||
       lds > 163840 - 20 * 1024)
     return fail(h, PSBA_E_INVALID, "dense solve supports 6*nCams <= 480 for now (got %d)", d.nA);
-  if (!g_chol_attr) {
+  if (!h->chol_attr_set) {
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     PSBA_HIP(h, hipFuncSetAttribute((const void *)k_chol_solve<3>, attr, 163840 - 20 * 1024));
     PSBA_HIP(h, hipFuncSetAttribute((const void *)k_chol_solve<4>, attr, 163840 - 20 * 1024));
-    g_chol_attr = true;
+    h->chol_attr_set = true;
   }
   {
     ProfScope ps(h, PSBA_K_CHOLESKY);

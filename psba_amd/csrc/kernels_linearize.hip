@@ -23,19 +23,22 @@ struct LinArgs {
   const int *iidx, *jidx, *ptr;
   const int4 *tile_desc;
   double *W, *PV, *campart;
+  double *camacc;  // GACC: [nC][27] global accumulators (zeroed before the launch)
   double *dbg_ex, *dbg_JA, *dbg_JB;
   double coeff, coeff_g;
   int nC, nTiles;
   int mode;  // development ablation (PSBA_LIN_MODE): 1 no camera atomics, 2 no W store, 3 no per-point sums
 };
 
-template <bool DUMP>
+// GACC: many cameras -- the 27 sums per camera do not fit the LDS, so every observation adds its
+// terms to global accumulators with fp64 atomics (k_cam_finalize then expands and scales them).
+template <bool DUMP, bool GACC>
 __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   __shared__ double sBE[TILE_OBS][8];  // B(6) | e(2) per observation of the tile
   __shared__ double sW[TILE_OBS * 19];  // W blocks of the tile
   extern __shared__ double sAcc[];     // [nC][27]
   const int tid = threadIdx.x;
-  const int nAcc = p.nC * CAM_ACC;
+  const int nAcc = GACC ? 0 : p.nC * CAM_ACC;
   for (int t = tid; t < nAcc; t += TILE_OBS) sAcc[t] = 0.0;
   __syncthreads();
 
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
       sBE[tid][6] = e[0];
       sBE[tid][7] = e[1];
       // camera sums: upper triangle of A^T A, then A^T e
-      double *acc = sAcc + CAM_ACC * j;
+      double *acc = (GACC ? p.camacc : sAcc) + CAM_ACC * (size_t)j;
       int k = 0;
       if (p.mode != 1) {
 #pragma unroll
@@ -147,8 +150,25 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
     }
     __syncthreads();
   }
+  if (GACC) return;
   double *slab = p.campart + (size_t)blockIdx.x * nAcc;
   for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
+}
+
+// GACC: expands the packed upper triangle of U_j to the full 6x6 and scales (U by coeff, g_a by coeff_g)
+__global__ __launch_bounds__(256) void k_cam_finalize(const double *camacc, int nC, double coeff, double coeff_g,
+                                                      double *U, double *ga) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 42 * nC) return;
+  const int j = t / 42, e = t % 42;
+  const double *src = camacc + (size_t)j * CAM_ACC;
+  if (e < 36) {
+    const int r = e / 6, c = e % 6;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    U[36 * (size_t)j + e] = coeff * src[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+  } else {
+    ga[6 * (size_t)j + e - 36] = coeff_g * src[21 + e - 36];
+  }
 }
 
 // one workgroup (1024 threads = 32 slab sequences x 32 entries) per camera: sums the partial
@@ -262,6 +282,7 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
   a.W = ahead ? h->W_alt : h->W;
   a.PV = ahead ? h->PV_alt : h->PV;
   a.campart = h->campart;
+  a.camacc = h->camacc;
   a.dbg_ex = h->dbg_ex;
   a.dbg_JA = h->dbg_JA;
   a.dbg_JB = h->dbg_JB;
@@ -273,15 +294,34 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
     const char *m = getenv("PSBA_LIN_MODE");
     a.mode = m ? atoi(m) : 0;
   }
-  const size_t lds = sizeof(double) * CAM_ACC * (size_t)d.nC;
+  const size_t lds = h->cam_global ? 0 : sizeof(double) * CAM_ACC * (size_t)d.nC;
+  // static LDS of the kernel is ~54 KiB: beyond 64 KiB in all, the dynamic part needs the attribute
+  if (!h->lin_attr_set && lds > 8 * 1024) {
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize<true, false>, attr, 100 * 1024));
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize<false, false>, attr, 100 * 1024));
+    h->lin_attr_set = true;
+  }
+  double *Uo = ahead ? h->U_alt : h->U, *gao = ahead ? h->ga_alt : h->ga;
   {
     ProfScope ps(h, PSBA_K_LINEARIZE);
-    if (dump)
-      hipLaunchKernelGGL(k_linearize<true>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
-    else
-      hipLaunchKernelGGL(k_linearize<false>, dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
-    hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, h->nPart,
-                       d.nC, h->coeff, h->coeff_g, ahead ? h->U_alt : h->U, ahead ? h->ga_alt : h->ga);
+    if (h->cam_global) {
+      PSBA_HIP(h, hipMemsetAsync(h->camacc, 0, sizeof(double) * CAM_ACC * (size_t)d.nC, h->stream));
+      const int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+      if (dump)
+        hipLaunchKernelGGL((k_linearize<true, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      else
+        hipLaunchKernelGGL((k_linearize<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      hipLaunchKernelGGL(k_cam_finalize, dim3((42 * d.nC + 255) / 256), dim3(256), 0, h->stream, h->camacc, d.nC,
+                         h->coeff, h->coeff_g, Uo, gao);
+    } else {
+      if (dump)
+        hipLaunchKernelGGL((k_linearize<true, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+      else
+        hipLaunchKernelGGL((k_linearize<false, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+      hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, h->nPart, d.nC, h->coeff,
+                         h->coeff_g, Uo, gao);
+    }
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

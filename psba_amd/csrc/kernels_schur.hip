@@ -315,10 +315,10 @@ struct SchurReduceArgs {
   double *packed;
 };
 
-// sums the slabs of each camera-row group (fixed order: four interleaved slab sequences, then
+// sums the slabs of each camera-row group (fixed order: eight interleaved slab sequences, then
 // their sum), adds blockdiag(U) + mu_add I and g_a, and writes the padded row-major S (both
-// block triangles) and the e_a row.  Workgroups walk the slabs in storage order (64
-// consecutive doubles x 4 slab sequences each; a group's partition is a multiple of 576
+// block triangles) and the e_a row.  Workgroups walk the slabs in storage order (32
+// consecutive pairs of doubles x 8 slab sequences each; a group's partition is a multiple of 576
 // doubles, so a workgroup never straddles groups) and scatter the few results.
 __device__ __forceinline__ void reduce_first_diag_block(const SchurReduceArgs &p, Factor32Lds &s) {
   const int tid = threadIdx.x, nC = p.nA / 6;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void reduce_first_diag_block(const SchurReduceArgs &p
 }
 
 __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
-  __shared__ double sAcc[4][64];
+  __shared__ double2 sAcc[8][32];
   __shared__ Factor32Lds sF;
   if ((int)blockIdx.x == p.diag_wg) {
     reduce_first_diag_block(p, sF);
@@ -364,30 +364,42 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   if (!p.packed)
     write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                   (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
-  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + o;  // slot 36 * (global position) + rc
+  // a workgroup owns 32 consecutive pairs of doubles (512 bytes of every slab of its group: 36 is
+  // even, so a pair never straddles a block, and a partition is a multiple of 16 blocks = 9 x 32
+  // pairs, so a workgroup never straddles groups); eight interleaved slab sequences, 16-byte loads,
+  // four of them in flight per thread
+  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int e2 = blockIdx.x * 32 + o;  // pair 18 * (global position) + rc / 2
   int g = 0;
-  while (g + 1 < p.nGroups && blockIdx.x * 64 >= 36 * p.gpos0[g + 1]) g++;
+  while (g + 1 < p.nGroups && blockIdx.x * 32 >= 18 * p.gpos0[g + 1]) g++;
   const int n = p.gnwg[g];
-  const size_t stride = (size_t)36 * p.gnblk[g];
-  const double *s = p.slab + p.gslab[g] + (e - 36 * p.gpos0[g]);
-  double acc = 0.0;
+  const size_t stride = (size_t)18 * p.gnblk[g];  // in pairs
+  const double2 *s = reinterpret_cast<const double2 *>(p.slab + p.gslab[g]) + (e2 - 18 * p.gpos0[g]);
+  double2 acc = make_double2(0.0, 0.0);
   int k = q;
-  for (; k + 12 < n; k += 16) {
-    const double x0 = s[(size_t)k * stride];
-    const double x1 = s[(size_t)(k + 4) * stride];
-    const double x2 = s[(size_t)(k + 8) * stride];
-    const double x3 = s[(size_t)(k + 12) * stride];
-    acc += x0;
-    acc += x1;
-    acc += x2;
-    acc += x3;
+  for (; k + 24 < n; k += 32) {
+    const double2 x0 = s[(size_t)k * stride];
+    const double2 x1 = s[(size_t)(k + 8) * stride];
+    const double2 x2 = s[(size_t)(k + 16) * stride];
+    const double2 x3 = s[(size_t)(k + 24) * stride];
+    acc.x += x0.x; acc.y += x0.y;
+    acc.x += x1.x; acc.y += x1.y;
+    acc.x += x2.x; acc.y += x2.y;
+    acc.x += x3.x; acc.y += x3.y;
   }
-  for (; k < n; k += 4) acc += s[(size_t)k * stride];
+  for (; k < n; k += 8) {
+    const double2 x = s[(size_t)k * stride];
+    acc.x += x.x; acc.y += x.y;
+  }
   sAcc[q][o] = acc;
   __syncthreads();
-  if (q != 0) return;
-  acc = ((sAcc[0][o] + sAcc[1][o]) + sAcc[2][o]) + sAcc[3][o];
+  if (threadIdx.x >= 64) return;
+  // one thread per double from here
+  const int po = threadIdx.x >> 1, hi = threadIdx.x & 1;
+  double sum = 0.0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) sum += hi ? sAcc[t][po].y : sAcc[t][po].x;
+  const int e = 2 * (blockIdx.x * 32 + po) + hi;  // slot 36 * (global position) + rc
   const int jk = p.posblock[e / 36];
   const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
   int ea_slot = -1;  // a diagonal block holds its lower triangle; six upper slots carry e_a, the rest is unused
@@ -399,23 +411,23 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   const bool unused = jk < 0 || (j == jb && c > r && ea_slot < 0);
   if (!unused) {
     if (ea_slot >= 0) {
-      acc += p.ga[6 * j + ea_slot];
+      sum += p.ga[6 * j + ea_slot];
     } else if (j == jb) {
-      acc += p.U[36 * j + rc];
-      if (r == c) acc += p.mu_add;
+      sum += p.U[36 * j + rc];
+      if (r == c) sum += p.mu_add;
     }
   }
   if (p.packed) {
-    p.packed[e] = unused ? 0.0 : acc;
+    p.packed[e] = unused ? 0.0 : sum;
     return;
   }
   if (unused) return;
   if (ea_slot >= 0) {
-    p.ea[6 * j + ea_slot] = acc;
+    p.ea[6 * j + ea_slot] = sum;
     return;
   }
-  p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = acc;
-  p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = acc;
+  p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = sum;
+  p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = sum;
 }
 
 // after the all-reduce of the packed sums: scatter them into the padded row-major S (both block
@@ -600,42 +612,46 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   const size_t lds = sizeof(double) * BLK_STRIDE * (size_t)worst;
   const int rgrid = 36 * r.gpos0[h->nGroups] / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
   r.diag_wg = fuse_diag ? rgrid : -1;
+  // timing classes: PSBA_K_SCHUR alone = one span over both kernels (S exists only after the
+  // reduce: that pair is the graded kernel); with PSBA_K_SCHUR_REDUCE also on, each kernel by itself
+  const bool pair = (h->prof & (1u << PSBA_K_SCHUR)) && !(h->prof & (1u << PSBA_K_SCHUR_REDUCE));
   {
-    ProfScope ps(h, PSBA_K_SCHUR);
-    const char *m = getenv("PSBA_SCHUR_MODE");
-    const int mode = m ? atoi(m) : 0;
-    const dim3 G(h->nWg), B(SCHUR_THREADS);
-    if (dump)
-      hipLaunchKernelGGL((k_schur_lds<true, 0>), G, B, lds, h->stream, a);
-    else if (mode == 1)
-      hipLaunchKernelGGL((k_schur_lds<false, 1>), G, B, lds, h->stream, a);
-    else if (mode == 2)
-      hipLaunchKernelGGL((k_schur_lds<false, 2>), G, B, lds, h->stream, a);
-    else if (mode == 3)
-      hipLaunchKernelGGL((k_schur_lds<false, 3>), G, B, lds, h->stream, a);
-    else if (mode == 4)
-      hipLaunchKernelGGL((k_schur_lds<false, 4>), G, B, lds, h->stream, a);
-    else
-      hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
-  }
-  PSBA_HIP(h, hipGetLastError());
-  {
-    ProfScope ps(h, PSBA_K_SCHUR_REDUCE);
-    hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid + (r.diag_wg >= 0 ? 1 : 0)), dim3(256), 0, h->stream, r);
+    ProfScope pp(h, pair ? PSBA_K_SCHUR : -1);
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR);
+      const char *m = getenv("PSBA_SCHUR_MODE");
+      const int mode = m ? atoi(m) : 0;
+      const dim3 G(h->nWg), B(SCHUR_THREADS);
+      if (dump)
+        hipLaunchKernelGGL((k_schur_lds<true, 0>), G, B, lds, h->stream, a);
+      else if (mode == 1)
+        hipLaunchKernelGGL((k_schur_lds<false, 1>), G, B, lds, h->stream, a);
+      else if (mode == 2)
+        hipLaunchKernelGGL((k_schur_lds<false, 2>), G, B, lds, h->stream, a);
+      else if (mode == 3)
+        hipLaunchKernelGGL((k_schur_lds<false, 3>), G, B, lds, h->stream, a);
+      else if (mode == 4)
+        hipLaunchKernelGGL((k_schur_lds<false, 4>), G, B, lds, h->stream, a);
+      else
+        hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
+    }
+    PSBA_HIP(h, hipGetLastError());
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR_REDUCE);
+      hipLaunchKernelGGL(k_schur_reduce, dim3(rgrid + (r.diag_wg >= 0 ? 1 : 0)), dim3(256), 0, h->stream, r);
+    }
   }
   h->diag_done = r.diag_wg >= 0;
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
 }
 
-static bool g_lds_attr_set = false;
-
 int launch_schur(psba_ctx *h, double mu, bool dump) {
   h->try_id++;
   h->diag_done = false;
   h->packed_pending = false;  // status words are generation stamps: nothing to zero
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
-    if (!g_lds_attr_set) {
+    if (!h->lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition
       const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<true, 0>, attr, dyn));
@@ -644,7 +660,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 2>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 3>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 4>, attr, dyn));
-      g_lds_attr_set = true;
+      h->lds_attr_set = true;
     }
     return launch_schur_lds(h, mu, dump);
   }
@@ -669,20 +685,36 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   a.try_id = h->try_id;
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 1) * h->n32, h->stream));
   int grid = d.nTiles < 2048 ? d.nTiles : 2048;
-  const size_t lds = sizeof(double) * (size_t)d.nA;
-  {
-    ProfScope ps(h, PSBA_K_SCHUR);
-    if (dump)
-      hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
-    else
-      hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+  const size_t lds = sizeof(double) * (size_t)d.nA;  // e_a accumulators of the workgroup
+  if (lds > 100 * 1024)
+    return fail(h, PSBA_E_INVALID, "global-atomic S assembly: 6 nCams = %d needs %zu B of LDS for e_a (> 100 KiB)",
+                d.nA, lds);
+  if (!h->atomic_attr_set && lds > 8 * 1024) {
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_atomic<true>, attr, 100 * 1024));
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_atomic<false>, attr, 100 * 1024));
+    h->atomic_attr_set = true;
   }
+  const bool pair = (h->prof & (1u << PSBA_K_SCHUR)) && !(h->prof & (1u << PSBA_K_SCHUR_REDUCE));
   const double mu_add = h->rank == 0 ? mu : 0.0;
   size_t n2 = (size_t)d.nA * d.nA;
-  int fgrid = (int)((n2 + 255) / 256);
-  if (fgrid > 1024) fgrid = 1024;
-  hipLaunchKernelGGL(k_schur_finalize, dim3(fgrid), dim3(256), 0, h->stream, a.S, a.ea, h->U, h->ga,
-                     mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0, h->scal, h->status, h->try_id);
+  size_t fg = (n2 + 255) / 256;
+  const int fgrid = fg > 4096 ? 4096 : (int)fg;
+  {
+    ProfScope pp(h, pair ? PSBA_K_SCHUR : -1);
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR);
+      if (dump)
+        hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+      else
+        hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+    }
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR_REDUCE);
+      hipLaunchKernelGGL(k_schur_finalize, dim3(fgrid), dim3(256), 0, h->stream, a.S, a.ea, h->U, h->ga,
+                         mu_add, d.nA, h->n32, h->rank == 0 ? 1.0 : 0.0, h->scal, h->status, h->try_id);
+    }
+  }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;
 }

@@ -34,7 +34,7 @@ int fail(psba_ctx *h, int code, const char *fmt, ...) {
 }
 
 ProfScope::ProfScope(psba_ctx *hh, int kind) : h(hh) {
-  if (!(h->prof & (1u << kind))) return;
+  if (kind < 0 || !(h->prof & (1u << kind))) return;
   if (h->spans_used == h->spans.size()) {
     psba_ctx::Span s;
     s.kind = kind;
@@ -53,9 +53,12 @@ ProfScope::~ProfScope() {
 
 }  // namespace psba
 
-#define CHECK_H(h)                 \
-  do {                             \
-    if (!(h)) return PSBA_E_INVALID; \
+// every entry point makes the handle's device current: a host may keep handles on several GPUs
+// in one process, or call from a thread whose current device is another one
+#define CHECK_H(h)                        \
+  do {                                    \
+    if (!(h)) return PSBA_E_INVALID;      \
+    (void)hipSetDevice((h)->device);      \
   } while (0)
 #define NEED(h, cond, what)                                             \
   do {                                                                  \
@@ -111,6 +114,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->U);
   dev_free(h->ga);
   dev_free(h->campart);
+  dev_free(h->camacc);
   dev_free(h->red);
   dev_free(h->items);
   dev_free(h->wg);
@@ -183,6 +187,13 @@ int psba_destroy(psba_handle h) {
   return PSBA_OK;
 }
 
+int psba_schur_path(psba_handle h, int *path) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (path) *path = (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) ? 0 : 1;
+  return PSBA_OK;
+}
+
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
@@ -241,9 +252,9 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   d.nT = d.nA + d.nB;
   d.nTiles = (int)tile_pt.size() - 1;
   d.maxTrack = maxTrack;
-  if ((size_t)CAM_ACC * nCams * sizeof(double) > 96 * 1024)
-    return fail(h, PSBA_E_INVALID, "nCams = %d needs %zu B of LDS camera accumulators; > 96 KiB "
-                "not supported yet", nCams, (size_t)CAM_ACC * nCams * sizeof(double));
+  // K1 keeps 27 accumulators per camera in LDS while they fit beside its tile buffers (nC <= 455);
+  // beyond that its camera sums go to global memory with fp64 atomics
+  h->cam_global = (size_t)CAM_ACC * nCams * sizeof(double) > 96 * 1024 || getenv("PSBA_LIN_GLOBAL_ACC");
   h->d = d;
   h->nPart = d.nTiles < 512 ? d.nTiles : 512;
   if (const char *e = getenv("PSBA_LIN_GRID")) h->nPart = atoi(e) > 0 && atoi(e) < d.nTiles ? atoi(e) : d.nTiles;
@@ -275,7 +286,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
   TRY(dev_alloc(h, &h->ga_alt, (size_t)d.nA));
   h->ahead = h->lin_is_ahead = false;
-  TRY(dev_alloc(h, &h->campart, (size_t)h->nPart * d.nC * CAM_ACC));
+  TRY(dev_alloc(h, &h->campart, h->cam_global ? 1 : (size_t)h->nPart * d.nC * CAM_ACC));
+  if (h->cam_global) TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * CAM_ACC));
   h->n32 = (d.nA + 31) / 32 * 32;
   // rows [0, n32 + 16) are the reduce buffer proper; n32 more rows below it are the working
   // space of the identity rows the panel chain carries along (kernels_chol_graph.hip)
@@ -309,6 +321,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
                 h->nGroups, h->nWg, plan.real_items, plan.items.size(),
                 plan.items.size() ? (double)plan.real_items / (double)plan.items.size() : 1.0,
                 8e-6 * (double)plan.slab_doubles);
+    } else if (!getenv("PSBA_QUIET")) {
+      // no silent cliff: say which route K2 takes (psba_schur_path returns the same)
+      fprintf(stderr, "[psba] K2: the lower block triangle of S (%d cameras) does not split into <= %d "
+              "LDS-sized camera-row groups; using the global-atomic assembly kernel\n", nCams, MAX_GROUPS);
     }
   }
   auto H2D = [&](void *dst, const void *src, size_t bytes) {

@@ -91,6 +91,10 @@ struct psba_ctx {
   hipEvent_t scal_event = nullptr;  // recorded behind the scalar copy of psba_backsub_async
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
   int nPart = 0;
+  // many cameras (the 27 per-camera accumulators no longer fit a workgroup's LDS): K1 adds its
+  // camera sums with global fp64 atomics into camacc [nC][27] (zeroed per launch) instead
+  bool cam_global = false;
+  double *camacc = nullptr;
   // padded reduce buffer Lw[(n32+16)][n32], n32 = nA rounded up to 32: rows < nA = S (row stride
   // n32), rows nA..n32-1 identity padding, row n32 = ea, rows above zero (S_buffer, eab_buffer)
   double *red = nullptr;
@@ -134,6 +138,10 @@ struct psba_ctx {
   // debug dumps for the sba_func.h mirror (allocated on first use)
   double *dbg_ex = nullptr, *dbg_JA = nullptr, *dbg_JB = nullptr, *dbg_Y = nullptr,
          *dbg_Vinv = nullptr, *dbg_eb = nullptr;
+
+  // kernels whose dynamic LDS exceeds 64 KiB need hipFuncSetAttribute once per device: kept per
+  // handle (one handle = one device), not per process
+  bool lds_attr_set = false, atomic_attr_set = false, chol_attr_set = false, lin_attr_set = false;
 
   // ---- state ----
   bool uploaded = false, linearized = false, assembled = false, solved = false, backsubbed = false;

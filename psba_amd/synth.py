@@ -84,13 +84,25 @@ def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, n
     k = min_track + rng.geometric(1.0 / (1.0 + extra), size=n_pts) - 1
     k = np.clip(k, min_track, max_track)
     iidx = np.repeat(np.arange(n_pts, dtype=np.int32), k)
-    # k distinct cameras per point, ascending: rank random keys row-wise
+    # k distinct cameras per point, ascending
     jidx = np.empty(iidx.size, dtype=np.int32)
     off = np.concatenate([[0], np.cumsum(k)])
     for kk in np.unique(k):
         rows = np.nonzero(k == kk)[0]
-        keys = rng.random((rows.size, n_cams))
-        pick = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
+        if n_cams > 256 and 4 * kk < n_cams:
+            # many cameras, short tracks: draw indices and redraw the few rows with repeats (the
+            # dense rows x cameras key matrix below would be rows x n_cams doubles)
+            pick = np.sort(rng.integers(0, n_cams, size=(rows.size, kk)), axis=1)
+            while True:
+                bad = np.nonzero((np.diff(pick, axis=1) == 0).any(axis=1))[0]
+                if bad.size == 0:
+                    break
+                pick[bad] = np.sort(rng.integers(0, n_cams, size=(bad.size, kk)), axis=1)
+            pick = pick.astype(np.int32)
+        else:
+            # rank random keys row-wise
+            keys = rng.random((rows.size, n_cams))
+            pick = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
         dest = (off[rows][:, None] + np.arange(kk)[None, :]).reshape(-1)
         jidx[dest] = pick.reshape(-1)
     true_cams = np.concatenate([np.zeros((n_cams, 3)), t], 1)
@@ -112,3 +124,13 @@ def venice_shaped(n_pts=64053, seed=0x5BA0 + 4, shard=0):
 def trafalgar50_shaped(seed=0x5BA0 + 3, shard=0):
     """Trafalgar-50-20431-shaped: 50 cameras, 20431 points, mean track 3.62."""
     return make_problem(50, 20431, 3.62, seed, shard=shard)
+
+
+def cfg5(n_pts=2_000_000, seed=0x5BA5, shard=0, n_cams=2000):
+    """BASELINE configs[4] as SURVEY 8(d) specifies it: 2000 cameras on a circle of radius 10
+    looking at the origin, f = 1000, points uniform in the unit ball, each seen by exactly 10
+    cameras drawn uniformly (every camera has the whole ball at positive depth), 1 px noise,
+    initial parameters = truth + N(0, 1e-3) (cameras) / N(0, 1e-2) (points); seed 0x5BA5.
+    n_pts scales the problem down for time-bound runs (the camera count, hence the 12 000 x 12 000
+    dense S, stays)."""
+    return make_problem(n_cams, n_pts, 10.0, seed, min_track=10, max_track=10, shard=shard)

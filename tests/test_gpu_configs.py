@@ -172,3 +172,72 @@ def test_levmar_on_the_other_bundled_sets(cams, pts, gpu):
     cams_out, pts_out = gpu.get_params()
     ex = Oracle(prob).exQT(cams=cams_out, pts=pts_out)
     assert abs(ex @ ex - res.final_err) <= 1e-9 * res.final_err + 1e-14 * ores.init_err
+
+
+@pytest.mark.parametrize("n_cams,k1_global", [(300, False), (455, False), (460, True)])
+def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global):
+    """Up to 455 cameras K1 keeps its 27 per-camera sums in LDS (more than 64 KiB of dynamic LDS
+    from ~270 cameras on), beyond that it adds them to global memory with fp64 atomics; K2 is on its
+    global-atomic route at all three sizes (psba_schur_path says so).  S / ea / U / g against the
+    oracle, the solve against LAPACK on the oracle's S."""
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=n_cams, n_pts=4000, mean_track=6.0, seed=7 + n_cams)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    assert gpu.schur_path() == 1
+    lin = o.linearize()
+    close(gpu.compute_U(1.0), lin["U"], 1e-11, "U")
+    close(gpu.compute_V(1.0), lin["V"], 1e-11, "V")
+    close(gpu.compute_g(1.0), lin["g"], 1e-11, "g")
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    gpu.update_UV(mu)
+    S = gpu.compute_S()
+    close(S, sch["S"], 1e-11, "S")
+    close(gpu.compute_ea(), sch["eab"][: o.nA], 1e-10, "ea")
+    rc, dpa = gpu.SPDinv_matVec()
+    assert rc == 0
+    ref = np.linalg.solve(sch["S"], sch["eab"][: o.nA])
+    close(dpa, ref, 1e-8, "dpa")
+    gpu.restore_UVdiag()
+    gpu.upload_problem(prob)
+    res, log = gpu.levmar(max_iter=3, tr_handoff=False)
+    acc = log[log[:, 4] > 0]
+    assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
+
+
+def test_cfg5_scaled_two_thousand_cameras(gpu):
+    """BASELINE configs[4] with the point count scaled down (2000 cameras x 20 000 points x
+    200 000 observations; synth.cfg5, seed 0x5BA5): the 12 000 x 12 000 dense S goes through the
+    unfused MFMA panel chain.  The oracle's dense solve would take minutes at this size, so the
+    checks are size-independent properties: S symmetric, ||S dpa - ea|| at rounding level, dpa
+    against LAPACK on the same S, U / g / ea against the oracle (cheap), and LM decreases the cost."""
+    import psba_amd.synth as synth
+    prob = synth.cfg5(n_pts=20000)
+    assert (prob["nC"], prob["nO"]) == (2000, 200000)
+    o = Oracle(prob)
+    gpu.upload_problem(prob)
+    assert gpu.schur_path() == 1
+    lin = o.linearize()
+    close(gpu.compute_U(1.0), lin["U"], 1e-11, "U")
+    close(gpu.compute_g(1.0), lin["g"], 1e-11, "g")
+    mu = 1e-3 * lin["maxdiag"]
+    gpu.update_UV(mu)
+    S = gpu.compute_S()
+    ea = gpu.compute_ea()
+    sch = o.schur(lin, mu)
+    close(ea, sch["eab"][: o.nA], 1e-10, "ea")
+    close(S, sch["S"], 1e-11, "S")
+    assert np.abs(S - S.T).max() <= 1e-14 * np.abs(S).max()
+    rc, dpa = gpu.SPDinv_matVec()
+    assert rc == 0
+    r = S @ dpa - ea
+    scale = np.abs(S).sum(axis=1).max() * np.abs(dpa).max() + np.abs(ea).max()  # inf-norms
+    assert np.abs(r).max() <= 1e-12 * scale, np.abs(r).max() / scale
+    ref = np.linalg.solve(S, ea)
+    np.testing.assert_allclose(dpa, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+    gpu.restore_UVdiag()
+    gpu.upload_problem(prob)
+    res, log = gpu.levmar(max_iter=3, tr_handoff=False)
+    acc = log[log[:, 4] > 0]
+    assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
