@@ -8,14 +8,23 @@ then stalls (tries per iteration become rounding noise), so the K tim
 as segments of at most --segment (10) iterations, each segment restarting from the initial
 parameters: every timed step is a productive iteration, and exactly K of them are timed.
 Workload (config.workload):
-  venice-shaped   52 cameras x 64053 points per GPU, mean track 5.42 -- the configuration the
-                  north star quotes its roofline target on; *synthetic-shaped*, because the real
-                  Venice-52-64053 point file is missing from the reference checkout (default)
+  venice-shaped   the 52 real cameras of data/Venice-52-64053-cams.txt x 64053 synthetic points,
+                  mean track 5.42 -- the configuration the north star quotes its roofline target
+                  on; *synthetic-shaped*, because the real Venice-52-64053 point file is missing
+                  from the reference checkout (default)
+  trafalgar50-shaped  the 50 real cameras of data/Trafalgar-50-20431-cams.txt x 20431 synthetic
+                  points (BASELINE configs[2]; its point file is missing too)
   54cams          the reference's data/54cams.txt + 54pts.txt, fixed K (BASELINE configs[1])
   trafalgar21     the reference's data/Trafalgar-21-11315-*.txt
-Multi-GPU: 3-D points are sharded over ranks (weak scaling: every rank owns one venice-shaped
-shard over the same 52 cameras), [S | ea] is summed with one RCCL all-reduce per damping try.
-Launch for N>1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+  cfg5            BASELINE configs[4]: 2000 cameras on a circle, 10 views per point, dense
+                  12000 x 12000 S on the MFMA panel chain; --cfg5-points scales the point count
+                  (default 200000 = 2 M observations; 2000000 is the full configuration)
+Multi-GPU: 3-D points are sharded over ranks and [S | ea] is summed with one RCCL all-reduce per
+damping try.  --scaling weak (default): every rank owns its own shard of the workload's size over
+the same cameras.  --scaling strong: ONE problem of the workload's size is split over the ranks
+with psba_partition_points -- BASELINE configs[3] is
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
+      bench.py --gpus 4 --scaling strong
 """
 import argparse
 import json
@@ -35,11 +44,14 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure quoted in SURVEY.md 8(d): fp64 v
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the graded kernel from the newest committed rocprofv3 PMC passes
-    (profiles/*_profile.json, written by scripts/summarize_prof.py): 2 x FETCH_SIZE (the gfx950
-    correction for wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None when no profile of
-    this workload is committed (bench.py itself cannot collect PMC counters)."""
+def pmc_traffic(workload, pair_us):
+    """HBM bytes per launch of the graded kernel pair (k_schur_lds + k_schur_reduce) from the newest
+    committed rocprofv3 PMC passes (profiles/r*_profile.json, written by scripts/summarize_prof.py):
+    2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes.  The factor 2 is the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md, section HBM ("FETCH_SIZE reports exactly 1/2 of the
+    bytes of a wide coalesced streaming read"); the raw counters are returned beside it.  A profile
+    whose recorded time for the pair differs from this run's by more than 10 % belongs to other
+    code: the traffic is then not quoted (bench.py itself cannot collect PMC counters)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_profile.json"))):
@@ -47,20 +59,36 @@ def pmc_traffic(workload):
             d = json.load(open(f))
             if d["bench"]["config"]["workload"] != workload:
                 continue
+            fetch = write = 0.0
+            seen = 0
             for name, c in d["pmc_avg_per_launch_KiB"].items():
-                if "k_schur_lds" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    best = ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.basename(f))
+                if ("k_schur_lds" in name or "k_schur_reduce" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    fetch += c["FETCH_SIZE"]
+                    write += c["WRITE_SIZE"]
+                    seen += 1
+            prof_us = sum(float(r["AverageNs"]) for r in d["kernel_stats"]
+                          if "k_schur_lds" in r["Name"] or "k_schur_reduce" in r["Name"]) / 1e3
+            if seen == 2:
+                best = {"bytes": (2 * fetch + write) * 1024.0, "file": os.path.basename(f), "fetch_kib_raw": fetch,
+                        "write_kib_raw": write, "profile_pair_us": prof_us, "git_head": d.get("git_head")}
         except Exception:
             continue
+    if best and not (0.9 * best["profile_pair_us"] <= pair_us <= 1.1 * best["profile_pair_us"]):
+        best["stale"] = True
     return best
 
 
-def load_workload(name, rank, nranks):
+def load_workload(name, rank, nranks, strong, cfg5_points):
+    """Returns (this rank's problem, data kind).  weak: shard `rank` of the generator (its own
+    points over the same cameras); strong: the one problem split with psba_partition_points."""
     data = os.path.join(ROOT, "tests", "golden", "data")
-    if name == "venice-shaped":
-        return synth.venice_shaped(shard=rank), "synthetic"
-    if name == "trafalgar50-shaped":
-        return synth.trafalgar50_shaped(shard=rank), "synthetic"
+    gens = {"venice-shaped": lambda sh: synth.venice_shaped(shard=sh),
+            "trafalgar50-shaped": lambda sh: synth.trafalgar50_shaped(shard=sh),
+            "cfg5": lambda sh: synth.cfg5(n_pts=cfg5_points, shard=sh)}
+    if name in gens:
+        if strong and nranks > 1:
+            return capi.shard_problem(gens[name](0), nranks, rank), "synthetic"
+        return gens[name](rank), "synthetic"
     if name == "54cams":
         kk = np.array([851.57945, 330.24755, 262.19500, 1.00169, 0.0])
         full = psba_amd.read_problem(os.path.join(data, "54cams.txt"), os.path.join(data, "54pts.txt"), kk)
@@ -69,6 +97,7 @@ def load_workload(name, rank, nranks):
                                      os.path.join(data, "Trafalgar-21-11315-pts.txt"))
     else:
         raise SystemExit(f"unknown workload {name}")
+    # a file is one problem: always split (strong scaling)
     return (capi.shard_problem(full, nranks, rank) if nranks > 1 else full), "reference data/*.txt"
 
 
@@ -81,6 +110,10 @@ def main():
     ap.add_argument("--segment", type=int, default=10, help="LM iterations per restart segment")
     ap.add_argument("--cpu-iters", type=int, default=30, help="LM iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cfg5-points", type=int, default=200000, help="points of the cfg5 workload (2000000 = full)")
+    ap.add_argument("--spread-segments", type=int, default=10,
+                    help="extra segments timed one by one after the K steps, for the median / spread fields")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,9 +130,10 @@ def main():
         # the data-path collective is RCCL inside the library, on the library's stream.
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    prob, data_kind = load_workload(args.workload, rank, world)
-    # PSBA_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (rehearsal of the N>1 path on a 1-GPU box)
-    h = psba_amd.Psba(0 if os.environ.get("PSBA_BENCH_ONE_DEVICE") else local_rank)
+    file_workload = args.workload in ("54cams", "trafalgar21")
+    strong = args.scaling == "strong" or file_workload
+    prob, data_kind = load_workload(args.workload, rank, world, strong, args.cfg5_points)
+    h = psba_amd.Psba(local_rank)  # one process per GPU (RCCL refuses two ranks on one device)
     if world > 1:
         uid = [psba_amd.Psba.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -159,6 +193,8 @@ def main():
                 times[-1] = float(t[0])
             if len(times) >= 12 and max(times[-3:]) <= 1.02 * min(times[-3:]):
                 break
+            if len(times) >= 3 and times[-1] > 0.25:  # long steps (cfg5): three segments are plenty
+                break
     # warmup: W untimed LM iterations
     if args.warmup > 0:
         run_steps(args.warmup)
@@ -181,37 +217,61 @@ def main():
     else:
         n_pts_total = prob["nP"]
     kern = {}
+    # PSBA_K_SCHUR alone in the mask = ONE span over k_schur_lds + k_schur_reduce: S does not exist
+    # before the reduce ends, so the pair is what the roofline is quoted on
     ms, n = h.profile_get(capi.K_SCHUR)
-    kern["schur"] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
-    h.profile_enable(True)  # untimed extra pass: per-kernel times of every class
+    pair_us = 1e3 * ms / max(n, 1)
+    # spread: further segments, each timed by itself (max over ranks), outside the K timed steps
+    seg_ms = []
+    h.profile_enable(0)
+    for _ in range(max(args.spread_segments, 0)):
+        barrier()
+        ts = time.perf_counter()
+        d_, _, _ = run_steps(args.segment)
+        dt = time.perf_counter() - ts
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        seg_ms.append(1e3 * dt / max(d_, 1))
+    h.profile_enable(True)  # untimed extra pass: per-kernel times of every class, each by itself
     h.profile_reset()
     run_steps(min(args.steps, args.segment))
     for k, name in enumerate(capi.KERNEL_NAMES):
         ms, n = h.profile_get(k)
-        if n and name != "schur":
+        if n:
             kern[name] = {"avg_us": 1e3 * ms / n, "launches": n}
     h.profile_enable(False)
 
     out = None
     if rank == 0:
         sch_bytes = h.algorithmic_bytes(capi.K_SCHUR)
-        sch_us = kern.get("schur", {"avg_us": float("nan")})["avg_us"]
+        sch_us = pair_us
         achieved = sch_bytes / (sch_us * 1e-6) / 1e9 if sch_us == sch_us and sch_us > 0 else float("nan")
+        seg_sorted = sorted(seg_ms)
         out = {
             "metric": "M-observations/sec through Jacobian+Schur build+solve (ms/LM-iter in ms_per_step)",
             "value": n_obs_total * steps_done / elapsed / 1e6,
             "unit": "M-obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (strong and world > 1) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": data_kind,
-            "config": {"workload": args.workload + ("" if world == 1 else f" x{world} shards"),
+            "config": {"workload": args.workload + ("" if world == 1 else
+                                                    (f" split over {world} ranks" if strong else f" x{world} shards")),
                        "n_cams": int(prob["nC"]), "n_pts": n_pts_total, "n_obs": n_obs_total,
                        "lm": "levmar, TR hand-off disabled", "parallelism": f"points sharded x{world}"},
             "steps_completed": steps_done, "damping_tries": tries_done, "lm_flag": res.flag, "segment": args.segment,
             "init_cost": res.init_err, "final_cost": res.final_err,
+            # the K timed steps are one sample; these are further segments of the same length timed one
+            # by one right after it (ms per LM iteration)
+            "ms_per_step_segments": ({"n": len(seg_ms), "median": seg_sorted[len(seg_sorted) // 2],
+                                      "min": seg_sorted[0], "max": seg_sorted[-1]} if seg_ms else None),
+            "schur_path": "lds-partitions" if h.schur_path() == 0 else "global-atomics",
             "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
-            "roofline": {"kernel": "schur assemble (W/Y/S/ea)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "schur assemble (W/Y/S/ea): k_schur_lds + k_schur_reduce, one HIP-event span over both",
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
                          "traffic": None},
@@ -225,11 +285,19 @@ def main():
                                    "achieved": sch_flops / (sch_us * 1e-6) / 1e12 if sch_us > 0 else None,
                                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": sch_flops / (sch_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if sch_us > 0 else None}
-        tr = pmc_traffic(args.workload) if world == 1 else None
+        tr = pmc_traffic(args.workload, pair_us) if world == 1 else None
         if tr:
-            out["roofline"]["traffic"] = tr[0]
-            out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/" + tr[1]
-        if world == 1 and not args.no_cpu_baseline:
+            out["roofline"]["traffic_profile"] = tr
+            if not tr.get("stale"):
+                out["roofline"]["traffic"] = tr["bytes"]
+                out["roofline"]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                                     "profiles/" + tr["file"] + " (2 x FETCH_SIZE + WRITE_SIZE)")
+        if args.workload == "cfg5" and not args.no_cpu_baseline:
+            # the oracle factors the dense 12000 x 12000 S with a plain triple loop: minutes per try
+            out["cpu_baseline"] = {"value": None, "unit": "M-obs/s", "cores": 1, "kind": "port",
+                                   "sample": "not run: one dense 12000 x 12000 Cholesky of the single-thread oracle "
+                                             "takes minutes, far beyond the bounded sample"}
+        elif world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_lib import Oracle  # the checker, timed as the CPU baseline ("port")
             tc, cpu_iters, ores = 0.0, 0, None

@@ -376,6 +376,43 @@ __global__ __launch_bounds__(512) void k_cholg_backward(double *Lw /* the factor
   if (bad) status[1] = status[3];
 }
 
+// backward solve for large matrices: the same block recurrence as k_cholg_backward, but one kernel
+// per 32-column block J (from the last to the first) spread over the chip instead of one workgroup
+// walking the whole factor (which reads 8 n^2 / 2 bytes through a single CU: 52 ms at n = 12 000).
+// Every workgroup forms x_J = L_JJ^-T y_J for itself (a 32x32 mat-vec with the stored inverse, from
+// LDS), then each thread applies y[c] -= sum_r L[J+r][c] x_J[r] to one column c < J; workgroup 0
+// stores x_J.  y_J is only read here and y[c < J] only written, so nothing races inside a launch.
+__global__ __launch_bounds__(256) void k_cholg_back_panel(double *Lw /* the factor buffer */, int ld, int n, int n32,
+                                                          int j, double *x, const double *linv, int *status) {
+  __shared__ double sLi[GB][GB + 1];
+  __shared__ double sY[GB], sX[GB];
+  const int tid = threadIdx.x;
+  double *y = Lw + (size_t)n32 * ld;
+  const double *Li = linv + (size_t)(j / GB) * GB * GB;
+  for (int t = tid; t < GB * GB; t += 256) sLi[t / GB][t % GB] = Li[t];
+  if (tid < GB) sY[tid] = y[j + tid];
+  __syncthreads();
+  if (tid < GB) {
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};  // (L_dd^-T y)[c] = sum_r Linv[r][c] y[r]
+#pragma unroll
+    for (int r = 0; r < GB; r++) a4[r & 3] += sLi[r][tid] * sY[r];
+    const double v = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    sX[tid] = v;
+    if (blockIdx.x == 0) {
+      if (j + tid < n) x[j + tid] = v;
+      if (!isfinite(v)) status[1] = status[3];
+    }
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c >= j) return;
+  const double *L = Lw + (size_t)j * ld + c;
+  double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < GB; r++) a4[r & 3] += L[(size_t)r * ld] * sX[r];
+  y[c] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
+}
+
 // dpa = L^-T y: the identity rows of the factor buffer hold L^-T (row i = e_i^T L^-T, upper
 // triangular) for all panels but the last, y = L^-1 e_a sits in row n32.  One wave per row, all
 // loads of a lane issued at once (n32 <= 640 on this path: at most ten 64-column strides).
@@ -468,10 +505,17 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
                        linv, h->status);
   } else {
-    int thr = (n32 + 63) / 64 * 64;
-    if (thr > 512) thr = 512;
-    hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
-                       h->status);
+    if (n32 > 2048 || getenv("PSBA_CHOL_BACK_PANELS")) {
+      // large matrices: one small kernel per block, all CUs (see k_cholg_back_panel)
+      for (int j = n32 - GB; j >= 0; j -= GB)
+        hipLaunchKernelGGL(k_cholg_back_panel, dim3(j / 256 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j, h->dp,
+                           linv, h->status);
+    } else {
+      int thr = (n32 + 63) / 64 * 64;
+      if (thr > 512) thr = 512;
+      hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
+                         h->status);
+    }
   }
 }
 

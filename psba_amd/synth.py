@@ -8,6 +8,8 @@ cameras drawn uniformly, points placed in front of their cameras, observations =
 the true point + N(0, 1 px), initial parameters = truth + small perturbation.  Every result made
 with this generator is labelled "synthetic-shaped", never with the dataset's name alone.
 """
+import os
+
 import numpy as np
 
 from .capi import Problem
@@ -116,14 +118,120 @@ def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, n
                    nC=n_cams, nP=n_pts, nO=int(iidx.size))
 
 
+def _rotmat(q):
+    """Rotation matrices [n,3,3] of unit quaternions [n,4] (scalar first)."""
+    s_, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - s_ * z), 2 * (x * z + s_ * y)], -1),
+                     np.stack([2 * (x * y + s_ * z), 1 - 2 * (x * x + z * z), 2 * (y * z - s_ * x)], -1),
+                     np.stack([2 * (x * z - s_ * y), 2 * (y * z + s_ * x), 1 - 2 * (x * x + y * y)], -1)], 1)
+
+
+def shaped_from_cams(cams_file, n_pts, mean_track, seed, shard=0, min_track=2, noise_px=1.0,
+                     cam_sigma=1e-3, pt_sigma=1e-2):
+    """SURVEY 8(d)'s stand-in for a dataset whose point file is missing: the REAL cameras of a
+    12-column sba cams file (K5, unit quaternion, t; data/*-cams.txt), the named number of points,
+    track length k ~ min_track + Geometric with the named mean (capped at the camera count), k
+    distinct cameras drawn uniformly, the point at the centroid of those cameras' centres + noise,
+    pushed along their mean optical axis until it has positive depth in all k views, observation
+    = the reference's projection of the true point + N(0, 1 px), initial parameters = truth +
+    a small perturbation.  Cameras (and their perturbation) depend on `seed` only, points and
+    observations also on `shard` (shards of one seed = pieces of one larger problem)."""
+    a = np.loadtxt(cams_file, comments="#", ndmin=2)
+    if a.shape[1] != 12:
+        raise ValueError(f"{cams_file}: expected 12 columns (K5 q4 t3), got {a.shape[1]}")
+    n_cams = a.shape[0]
+    K = a[:, :5].copy()
+    q = a[:, 5:9] / np.linalg.norm(a[:, 5:9], axis=1, keepdims=True)
+    q[q[:, 0] < 0] *= -1.0  # quat2vec's sign convention (PSBA/misc.cpp:38-43)
+    t = a[:, 9:12].copy()
+    R = _rotmat(q)
+    C = -np.einsum("jrc,jr->jc", R, t)  # camera centres: P = R M + t = R (M - C)
+    axis = R[:, 2, :]                     # optical axes in world coordinates
+    rng = np.random.default_rng([seed, 1 + shard])
+    rng_cam = np.random.default_rng([seed, 0])
+    extra = max(mean_track - min_track, 1e-9)
+    k = min_track + rng.geometric(1.0 / (1.0 + extra), size=n_pts) - 1
+    k = np.clip(k, min_track, n_cams)
+    iidx = np.repeat(np.arange(n_pts, dtype=np.int32), k)
+    jidx = np.empty(iidx.size, dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(k)])
+    for kk in np.unique(k):
+        rows = np.nonzero(k == kk)[0]
+        keys = rng.random((rows.size, n_cams))
+        pick = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
+        dest = (off[rows][:, None] + np.arange(kk)[None, :]).reshape(-1)
+        jidx[dest] = pick.reshape(-1)
+    spread = float(np.linalg.norm(C.std(axis=0)))
+    depth_min = 0.25 * spread
+    true_cams = np.concatenate([np.zeros((n_cams, 3)), t], 1)
+    noise = rng.normal(0, 0.5 * spread, (n_pts, 3))
+    M = np.zeros((n_pts, 3))
+    todo = np.arange(n_pts)
+    for attempt in range(40):
+        # centroid and mean optical axis of each point's cameras; push the point along that axis
+        # (doubling) until every view has it at positive depth
+        sel = np.zeros(n_pts, dtype=bool)
+        sel[todo] = True
+        obs = np.nonzero(sel[iidx])[0]
+        ii, jj = iidx[obs], jidx[obs]
+        cen = np.zeros((n_pts, 3))
+        axm = np.zeros((n_pts, 3))
+        np.add.at(cen, ii, C[jj])
+        np.add.at(axm, ii, axis[jj])
+        cen[todo] /= k[todo][:, None]
+        axm[todo] /= np.maximum(np.linalg.norm(axm[todo], axis=1, keepdims=True), 1e-12)
+        push = np.full(n_pts, 2.0 * spread)
+        worst = np.full(n_pts, np.inf)
+        for _ in range(8):
+            Mp = cen + noise + push[:, None] * axm
+            _, depth = project(K[jj], q[jj], true_cams[jj], Mp[ii])
+            worst[todo] = np.inf
+            np.minimum.at(worst, ii, depth)
+            bad = todo[worst[todo] < depth_min]
+            if bad.size == 0:
+                break
+            push[bad] *= 2.0
+        good = todo[worst[todo] >= depth_min]
+        M[good] = (cen + noise + push[:, None] * axm)[good]
+        todo = todo[worst[todo] < depth_min]
+        if todo.size == 0:
+            break
+        # cameras facing away from each other: draw another camera set (same track length) for the
+        # points that could not be placed; late attempts take cameras looking the same way as a
+        # random anchor camera
+        for i in todo:
+            if attempt < 30:
+                pick = np.sort(rng.choice(n_cams, size=k[i], replace=False))
+            else:
+                anchor = rng.integers(n_cams)
+                pick = np.sort(np.argsort(-(axis @ axis[anchor]))[: k[i]])
+            jidx[off[i]: off[i + 1]] = pick
+    if todo.size:
+        raise ValueError("could not place every point in front of its cameras")
+    xy, depth = project(K[jidx], q[jidx], true_cams[jidx], M[iidx])
+    assert np.all(depth > 0)
+    impts = xy + rng.normal(0, noise_px, xy.shape)
+    cams0 = true_cams + np.concatenate([rng_cam.normal(0, cam_sigma, (n_cams, 3)),
+                                        rng_cam.normal(0, cam_sigma, (n_cams, 3))], 1)
+    pts0 = M + rng.normal(0, pt_sigma, M.shape)
+    return Problem(K=K, initrot=q, cams=cams0, pts=pts0, impts=impts, iidx=iidx, jidx=jidx,
+                   nC=n_cams, nP=n_pts, nO=int(iidx.size))
+
+
+# the reference's bundled data/*.txt, copied as fixtures (the GPU box receives only this repository)
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
+
+
 def venice_shaped(n_pts=64053, seed=0x5BA0 + 4, shard=0):
-    """Venice-52-64053-shaped: 52 cameras, 64053 points, mean track 5.42."""
-    return make_problem(52, n_pts, 5.42, seed, shard=shard)
+    """Venice-52-64053-shaped (BASELINE configs[3]): the 52 real cameras of
+    data/Venice-52-64053-cams.txt, 64053 synthetic points, mean track 5.42."""
+    return shaped_from_cams(os.path.join(_DATA, "Venice-52-64053-cams.txt"), n_pts, 5.42, seed, shard=shard)
 
 
 def trafalgar50_shaped(seed=0x5BA0 + 3, shard=0):
-    """Trafalgar-50-20431-shaped: 50 cameras, 20431 points, mean track 3.62."""
-    return make_problem(50, 20431, 3.62, seed, shard=shard)
+    """Trafalgar-50-20431-shaped (BASELINE configs[2]): the 50 real cameras of
+    data/Trafalgar-50-20431-cams.txt, 20431 synthetic points, mean track 3.62."""
+    return shaped_from_cams(os.path.join(_DATA, "Trafalgar-50-20431-cams.txt"), 20431, 3.62, seed, shard=shard)
 
 
 def cfg5(n_pts=2_000_000, seed=0x5BA5, shard=0, n_cams=2000):

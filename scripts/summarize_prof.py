@@ -41,6 +41,13 @@ for r in stats:
                  f"{'' if w is None else f'{w:.0f}'} |")
 lines += ["", "bench.py line of the traced run (HIP-event timings inside bench.py):", "", "```json", json.dumps(bench, indent=1), "```"]
 open(os.path.join(dst, f"{out}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
-json.dump({"kernel_stats": stats, "pmc_avg_per_launch_KiB": pmc, "bench": bench},
+import subprocess
+try:
+    head = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "psba_amd", "bench.py"], text=True).strip())
+    head += "+dirty" if dirty else ""
+except Exception:
+    head = None
+json.dump({"git_head": head, "kernel_stats": stats, "pmc_avg_per_launch_KiB": pmc, "bench": bench},
           open(os.path.join(dst, f"{out}_profile.json"), "w"), indent=1)
 print("\n".join(lines[:22]))

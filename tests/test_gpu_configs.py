@@ -241,3 +241,27 @@ def test_cfg5_scaled_two_thousand_cameras(gpu):
     res, log = gpu.levmar(max_iter=3, tr_handoff=False)
     acc = log[log[:, 4] > 0]
     assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
+
+
+def test_panelwise_backward_solve(monkeypatch):
+    """PSBA_CHOL_BACK_PANELS=1 forces the backward solve large matrices take (one kernel per
+    32-column block over all CUs, k_cholg_back_panel) at a size the oracle solves quickly."""
+    import psba_amd
+    import psba_amd.synth as synth
+    monkeypatch.setenv("PSBA_CHOL_BACK_PANELS", "1")
+    prob = synth.make_problem(n_cams=130, n_pts=3000, mean_track=5.0, seed=77)
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, _ = o.solve(lin, sch)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    h.compute_S()
+    rc, dpa = h.SPDinv_matVec()
+    assert rc == 0
+    close(dpa, dp[: o.nA], 1e-9, "dpa")
+    close(h.compute_dpb(), dp, 1e-8, "dp")
+    h.close()
