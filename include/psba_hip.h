@@ -226,6 +226,19 @@ typedef struct {
 int psba_read_problem(const char *cams_file, const char *pts_file, const double *fixedK,
                       psba_problem *out);
 void psba_free_problem(psba_problem *p);
+/* The writer the reference declares and keeps commented out (printSBAMotionData /
+ * printSBAStructureData / printSBAData, PSBA/readparams.h:13-25; output filter vec2quat,
+ * PSBA/misc.cpp:60-85): cams file with one line per camera -- K5 when with_K != 0, then the full
+ * quaternion q_l(v) (x) initrot and t -- and pts file "X Y Z nframes {frame x y}...".  The files
+ * are valid input of psba_read_problem (which then returns initrot = that quaternion, v = 0). */
+int psba_write_problem(const char *cams_file, const char *pts_file, int nCams, int n3Dpts, int n2Dprojs,
+                       const double *Kparas, const double *initrot, const double *camsEx, const double *pts3D,
+                       const double *impts, const int *iidx, const int *jidx, int with_K);
+/* Bundle-Adjustment-in-the-Large text file -> sba cams / pts files in the reference's camera
+ * model (how its data/Trafalgar-* files relate to the public BAL sets): camera turned to look
+ * down +z, image y negated, K = (f,0,0,1,0); the radial terms k1, k2 are dropped (the reference
+ * has no distortion) and their largest magnitude is returned in *max_abs_k (may be NULL). */
+int psba_convert_bal(const char *bal_file, const char *cams_out, const char *pts_out, double *max_abs_k);
 
 /* ---- measurement ----------------------------------------------------------------------
  * HIP-event timing of the kernels launched by the fused verbs, on the handle's stream. */

@@ -5,6 +5,8 @@ package is only a ctypes binding to it for tests, bench.py and Python callers.  
 fallback: importing :mod:`psba_amd.capi` raises if the library has not been built, and creating
 a handle raises if no GPU is present.
 """
-from .capi import Psba, PsbaError, Problem, lib, lib_path, read_problem, partition_points  # noqa: F401
+from .capi import (Psba, PsbaError, Problem, lib, lib_path, read_problem, partition_points,  # noqa: F401
+                   write_problem, convert_bal)
 
-__all__ = ["Psba", "PsbaError", "Problem", "lib", "lib_path", "read_problem", "partition_points"]
+__all__ = ["Psba", "PsbaError", "Problem", "lib", "lib_path", "read_problem", "partition_points",
+           "write_problem", "convert_bal"]

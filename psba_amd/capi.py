@@ -105,6 +105,8 @@ SIGNATURES = [
     ("psba_profile_reset", C.c_int, [_h]),
     ("psba_profile_get", C.c_int, [_h, C.c_int, _dp, _ip]),
     ("psba_algorithmic_bytes", C.c_int, [_h, C.c_int, _dp]),
+    ("psba_write_problem", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
+    ("psba_convert_bal", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dp]),
     ("psba_schur_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
@@ -153,6 +155,27 @@ def read_problem(cams_file, pts_file, fixedK=None):
                   jidx=arr(cp.jidx, nO, (nO,)).astype(np.int32), nC=nC, nP=nP, nO=nO)
     lib.psba_free_problem(C.byref(cp))
     return out
+
+
+def write_problem(cams_file, pts_file, prob, cams=None, pts=None, with_K=True):
+    """psba_write_problem: the problem's data with the given (default: its own) parameters."""
+    c = _c(prob["cams"] if cams is None else cams)
+    p = _c(prob["pts"] if pts is None else pts)
+    K, rot, im = _c(prob["K"]), _c(prob["initrot"]), _c(prob["impts"])
+    ii, jj = _c(prob["iidx"], np.int32), _c(prob["jidx"], np.int32)
+    rc = lib.psba_write_problem(cams_file.encode(), pts_file.encode(), int(prob["nC"]), int(prob["nP"]),
+                                int(prob["nO"]), _d(K), _d(rot), _d(c), _d(p), _d(im), _i(ii), _i(jj), int(with_K))
+    if rc != 0:
+        raise PsbaError(rc, f"psba_write_problem({cams_file}, {pts_file}) failed")
+
+
+def convert_bal(bal_file, cams_out, pts_out):
+    """psba_convert_bal; returns the largest |k1|, |k2| that was dropped."""
+    k = C.c_double()
+    rc = lib.psba_convert_bal(bal_file.encode(), cams_out.encode(), pts_out.encode(), C.byref(k))
+    if rc != 0:
+        raise PsbaError(rc, f"psba_convert_bal({bal_file}) failed")
+    return k.value
 
 
 def partition_points(n_pts, iidx, nranks):

@@ -1,4 +1,4 @@
-// sba_io.cpp -- reader for the sba text format (host only).
+// sba_io.cpp -- reader, writer and BAL converter for the sba text format (host only).
 // Restates readInitialSBAEstimate and its helpers (reference PSBA/readparams.cpp:169-232,
 // 247-290,332-423,444-519) together with the quat2vec input filter (PSBA/misc.cpp:21-49) and
 // the parameter split the driver performs (PSBA/main.cpp:131-149; fixed-K variant
@@ -173,6 +173,118 @@ int psba_read_problem(const char *cams_file, const char *pts_file, const double 
     psba_free_problem(out);
     return PSBA_E_NOMEM;
   }
+  return PSBA_OK;
+}
+
+// ---- writer ------------------------------------------------------------------------------
+// The reference declares printSBAMotionData / printSBAStructureData / printSBAData and keeps them
+// commented out (PSBA/readparams.h:13-25); their output filter is vec2quat (PSBA/misc.cpp:60-85):
+// the optimised local rotation v is turned back into a full quaternion.  Here the local rotation
+// is composed onto initrot (q = q_l(v) (x) q0, the product the kernels use,
+// CL_files/compute_exQT.cl:36-49), so the files written are again valid input: reading them back
+// gives initrot = q and v = 0, i.e. the same cameras.  17 significant digits: doubles round-trip.
+int psba_write_problem(const char *cams_file, const char *pts_file, int nCams, int n3Dpts, int n2Dprojs,
+                       const double *Kparas, const double *initrot, const double *camsEx, const double *pts3D,
+                       const double *impts, const int *iidx, const int *jidx, int with_K) {
+  if (!cams_file || !pts_file || nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !initrot || !camsEx || !pts3D ||
+      !impts || !iidx || !jidx || (with_K && !Kparas))
+    return PSBA_E_INVALID;
+  FILE *fc = fopen(cams_file, "w");
+  if (!fc) return PSBA_E_IO;
+  for (int j = 0; j < nCams; j++) {
+    const double *v = camsEx + 6 * (size_t)j, *q0 = initrot + 4 * (size_t)j;
+    const double sl = std::sqrt(1.0 - v[0] * v[0] - v[1] * v[1] - v[2] * v[2]);
+    // Hamilton product (sl, v) (x) q0
+    double q[4] = {sl * q0[0] - (v[0] * q0[1] + v[1] * q0[2] + v[2] * q0[3]),
+                   sl * q0[1] + q0[0] * v[0] + (v[1] * q0[3] - v[2] * q0[2]),
+                   sl * q0[2] + q0[0] * v[1] + (v[2] * q0[1] - v[0] * q0[3]),
+                   sl * q0[3] + q0[0] * v[2] + (v[0] * q0[2] - v[1] * q0[1])};
+    if (with_K)
+      for (int k = 0; k < 5; k++) fprintf(fc, "%.17g ", Kparas[5 * (size_t)j + k]);
+    fprintf(fc, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", q[0], q[1], q[2], q[3], v[3], v[4], v[5]);
+  }
+  if (fclose(fc) != 0) return PSBA_E_IO;
+  FILE *fp = fopen(pts_file, "w");
+  if (!fp) return PSBA_E_IO;
+  int a = 0;
+  for (int i = 0; i < n3Dpts; i++) {
+    int b = a;
+    while (b < n2Dprojs && iidx[b] == i) b++;
+    fprintf(fp, "%.17g %.17g %.17g %d", pts3D[3 * (size_t)i], pts3D[3 * (size_t)i + 1], pts3D[3 * (size_t)i + 2], b - a);
+    for (; a < b; a++) fprintf(fp, " %d %.17g %.17g", jidx[a], impts[2 * (size_t)a], impts[2 * (size_t)a + 1]);
+    fprintf(fp, "\n");
+  }
+  const bool ok = a == n2Dprojs;  // observations must be point-major
+  if (fclose(fp) != 0 || !ok) return ok ? PSBA_E_IO : PSBA_E_INVALID;
+  return PSBA_OK;
+}
+
+// ---- Bundle-Adjustment-in-the-Large -> sba -------------------------------------------------
+// BAL text: "ncams npts nobs", nobs lines "cam point x y", then 9 numbers per camera (Rodrigues
+// vector r, translation t, focal f, radial k1 k2) and 3 per point, one number per line.  BAL's
+// camera looks down -z and projects p = -P / P.z, x = f p (1 + k1 |p|^2 + k2 |p|^4); the
+// reference's model looks down +z, divides by P.z and has no distortion.
+// With F = diag(1, -1, -1) (a half turn about x): R' = F R, t' = F t gives P' = F P, so
+// x' = f P'.x / P'.z equals BAL's x and y' equals minus BAL's y: the image y coordinates are
+// negated, K = (f, 0, 0, 1, 0) -- the layout of the bundled BAL-derived files
+// (data/Trafalgar-21-11315-cams.txt).  k1, k2 are dropped (the reference never applies
+// distortion, PSBA/main.cpp:73,102-103); *max_abs_k (may be NULL) returns the largest |k1|, |k2|
+// dropped so that the caller can judge it.  Observations are written point-major, cameras
+// ascending, which is what every consumer of the format assumes.
+int psba_convert_bal(const char *bal_file, const char *cams_out, const char *pts_out, double *max_abs_k) {
+  if (!bal_file || !cams_out || !pts_out) return PSBA_E_INVALID;
+  FILE *fb = fopen(bal_file, "r");
+  if (!fb) return PSBA_E_IO;
+  int nC = 0, nP = 0, nO = 0;
+  if (fscanf(fb, "%d %d %d", &nC, &nP, &nO) != 3 || nC <= 0 || nP <= 0 || nO <= 0) {
+    fclose(fb);
+    return PSBA_E_IO;
+  }
+  struct Ob { int pt, cam; double x, y; };
+  std::vector<Ob> obs((size_t)nO);
+  for (auto &o : obs)
+    if (fscanf(fb, "%d %d %lf %lf", &o.cam, &o.pt, &o.x, &o.y) != 4 || o.cam < 0 || o.cam >= nC || o.pt < 0 ||
+        o.pt >= nP) {
+      fclose(fb);
+      return PSBA_E_IO;
+    }
+  std::vector<double> cam((size_t)9 * nC), pt((size_t)3 * nP);
+  for (auto &v : cam)
+    if (fscanf(fb, "%lf", &v) != 1) { fclose(fb); return PSBA_E_IO; }
+  for (auto &v : pt)
+    if (fscanf(fb, "%lf", &v) != 1) { fclose(fb); return PSBA_E_IO; }
+  fclose(fb);
+  std::stable_sort(obs.begin(), obs.end(), [](const Ob &a, const Ob &b) { return a.pt != b.pt ? a.pt < b.pt : a.cam < b.cam; });
+  for (size_t k = 1; k < obs.size(); k++)
+    if (obs[k].pt == obs[k - 1].pt && obs[k].cam == obs[k - 1].cam) return PSBA_E_IO;
+  FILE *fc = fopen(cams_out, "w");
+  if (!fc) return PSBA_E_IO;
+  double kmax = 0.0;
+  for (int j = 0; j < nC; j++) {
+    const double *c = &cam[(size_t)9 * j];
+    const double th = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    // Rodrigues vector -> unit quaternion; sin(th/2)/th -> 1/2 as th -> 0
+    const double k = th > 1e-12 ? std::sin(0.5 * th) / th : 0.5;
+    const double q[4] = {std::cos(0.5 * th), k * c[0], k * c[1], k * c[2]};
+    // (0, 1, 0, 0) (x) q : the half turn about x applied after R
+    const double qf[4] = {-q[1], q[0], -q[3], q[2]};
+    fprintf(fc, "%.17g 0 0 1 0 %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", c[6], qf[0], qf[1], qf[2], qf[3], c[3],
+            -c[4], -c[5]);
+    kmax = std::max(kmax, std::max(std::fabs(c[7]), std::fabs(c[8])));
+  }
+  if (fclose(fc) != 0) return PSBA_E_IO;
+  if (max_abs_k) *max_abs_k = kmax;
+  FILE *fp = fopen(pts_out, "w");
+  if (!fp) return PSBA_E_IO;
+  size_t a = 0;
+  for (int i = 0; i < nP; i++) {
+    size_t b = a;
+    while (b < obs.size() && obs[b].pt == i) b++;
+    fprintf(fp, "%.17g %.17g %.17g %d", pt[(size_t)3 * i], pt[(size_t)3 * i + 1], pt[(size_t)3 * i + 2], (int)(b - a));
+    for (; a < b; a++) fprintf(fp, " %d %.17g %.17g", obs[a].cam, obs[a].x, -obs[a].y);
+    fprintf(fp, "\n");
+  }
+  if (fclose(fp) != 0) return PSBA_E_IO;
   return PSBA_OK;
 }
 
