@@ -196,6 +196,60 @@ void psba_lm_default_options(psba_lm_options *o);
 /* log rows: (itno, new ||e||^2, rho, mu, accepted{1,0,-1=solve failed}) per damping try */
 int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res, double *log);
 
+/* ---- the trust-region caller, PSBA/trust_region.cpp:49-595, and its extra operators -------
+ * (single rank; B = 2 J^T J, g = -2 J^T e through psba_linearize(h, 2, -2)). */
+/* compute_Jmultiply (PSBA/sba_func.cpp:19-75, CL_files/compute_Jmultiply.cl:6-52): J x for a host
+ * vector x[nT].  Jmul has 2 values per OBSERVATION (2 * n2Dprojs, observation order) -- the
+ * non-zeros, in the same order, of the reference's dense nP x nC x 2 grid. */
+int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul);
+/* what the loop needs of it: dots = (Jx1.Jx1, Jx1.Jx2, Jx2.Jx2); x2 NULL = x1
+ * (trust_region.cpp:125-126,166-176,209-211 take these dot products on the host) */
+int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dots[3]);
+/* g = [g_a ; g_b] of the last linearization (the host output of compute_g, sba_func.h:103-109) */
+int psba_get_gradient(psba_handle h, double *g);
+/* dp = [dpa ; dpb] of the last solve + back-substitution (host output of compute_dpb) */
+int psba_get_dp(psba_handle h, double *dp);
+/* dp_buffer <- dp, then compute_newp: proposed parameters = current + dp
+ * (trust_region.cpp:183-187); psba_residual(PSBA_PARAMS_NEW) evaluates them, psba_accept takes them */
+int psba_set_step(psba_handle h, const double *dp);
+/* the lambda estimate taken when S is not positive definite at lambda = 0
+ * (trust_region.cpp:341-363): S is assembled again without damping, factored by the modified
+ * Cholesky of PSBA/cl_cholmod.cpp:25-201 / CL_files/cholmod_blk.cl:87-846, and
+ * lambda = |sum_i E_i| / (6 nCams) with E = diag(L L^T) - diag(S).  info3 (may be NULL) =
+ * (delta, beta, number of block columns that took the one-column route).  reassemble = 0 skips
+ * the assembly and factors what the reduce buffer holds (psba_schur_assemble or
+ * psba_set_reduce_buffer before it): the hook the tests use to factor a chosen matrix. */
+int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3);
+
+typedef struct {
+  int max_iter;     /* literal 50, shared with levmar() through itno (trust_region.cpp:112) */
+  int start_itno;
+  int verbose;      /* print the reference's per-step line (trust_region.cpp:250) */
+  int log_cap;      /* rows available in log (6 doubles each), 0 = none */
+} psba_tr_options;
+
+typedef struct {
+  int flag;         /* PSBA_ITER_* */
+  int iters;        /* value of itno at exit */
+  int tries;        /* steps evaluated */
+  int chol_fail;    /* factorizations of S that failed (each followed by a larger lambda) */
+  double init_err, final_err, lambda, delta;
+  int n_log;
+  double seconds;
+} psba_tr_result;
+
+void psba_tr_default_options(psba_tr_options *o);
+/* log rows: (itno, ||e(p + step)||^2, rho, delta after the update, lambda, accepted{1,0}) per step */
+int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result *res, double *log);
+
+/* the driver's alternation, PSBA/main.cpp:193-208: levmar() until ITER_TURN_TO_TR, trust_region()
+ * until ITER_TURN_TO_LM, max_iter iterations in total */
+typedef struct {
+  int flag, iters, lm_calls, tr_calls;
+  double init_err, final_err, seconds;
+} psba_solve_result;
+int psba_solve(psba_handle h, int max_iter, int verbose, psba_solve_result *res);
+
 /* ---- multi-GPU: 3-D points sharded over ranks, one process per GPU -------------------- */
 /* contiguous point ranges balanced on observation count; pt_begin[nranks+1] */
 int psba_partition_points(int n3Dpts, const int *iidx, int n2Dprojs, int nranks, int *pt_begin);

@@ -569,7 +569,7 @@ int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
 
   memset(res, 0, sizeof(*res));
   double mu = 0, rho, p_L2 = 0, dp_L2, ex_L2, new_ex_L2;
-  int nu = 2, first = 1, gooditer = 0, tries = 0, itno = 0, nlog = 0;
+  int nu = 2, first = 1, gooditer = 0, tries = 0, itno = opts->start_itno, nlog = 0;
   int flag = ORC_ITER_CONTINUE;
   double t0;
 
@@ -685,5 +685,361 @@ int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
   res->n_log = nlog;
   free(ex); free(JA); free(JB); free(W); free(Y); free(U); free(V); free(Vinv); free(UVdiag);
   free(S); free(g); free(eab); free(dp); free(newcams); free(newpts);
+  return flag;
+}
+
+
+/* ======================================================================================== */
+/* trust-region caller                                                         */
+
+void orc_compute_Jmultiply(int nC, int nO, const double *JA, const double *JB, const int *iidx,
+                           const int *jidx, const double *x, double *out) {
+  const int nA = 6 * nC;
+  ORC_PAR_FOR
+  for (int a = 0; a < nO; a++) {
+    const double *xa = x + 6 * jidx[a], *xb = x + nA + 3 * iidx[a];
+    for (int k = 0; k < 2; k++) { /* compute_Jmultiply.cl:32-46: row k of A_ij, then of B_ij */
+      const double *A = JA + 12 * (size_t)a + 6 * k, *B = JB + 6 * (size_t)a + 3 * k;
+      double sum = 0;
+      for (int c = 0; c < 6; c++) sum += A[c] * xa[c];
+      for (int c = 0; c < 3; c++) sum += B[c] * xb[c];
+      out[2 * (size_t)a + k] = sum;
+    }
+  }
+}
+
+static double dot_n(int n, const double *a, const double *b) { /* PSBA/misc.cpp dotProduct */
+  double s = 0;
+  for (int i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+
+void orc_get_delta_beta(int n, const double *A, double *delta, double *beta) {
+  double xi = 0, gamma = 0; /* largest |off-diagonal|, largest |diagonal| */
+  for (int r = 0; r < n; r++) {
+    for (int c = 0; c < n; c++) {
+      double v = fabs(A[(size_t)r * n + c]);
+      if (r == c) {
+        if (v > gamma) gamma = v;
+      } else if (v > xi)
+        xi = v;
+    }
+  }
+  *delta = 1e-15 * fmax(xi + gamma, 1); /* cl_cholmod.cpp:163 */
+  double b = fmax(gamma, 1e-15);
+  b = fmax(b, xi / sqrt((double)n * n - 1));
+  *beta = sqrt(b);
+}
+
+/* one column of the modified factorization (cholmod_blk.cl:560-706: step1..step4) */
+static void cholmod_single_column(int n, double *M, int j, double beta, double delta, double *C) {
+  double d = M[(size_t)j * n + j];
+  for (int k = 0; k < j; k++) d -= M[(size_t)j * n + k] * M[(size_t)j * n + k];
+  d = fmax(fabs(d), delta);
+  double ljj = sqrt(d);
+  M[(size_t)j * n + j] = ljj;
+  int over = 0;
+  for (int i = j + 1; i < n; i++) {
+    double c = M[(size_t)i * n + j];
+    for (int k = 0; k < j; k++) c -= M[(size_t)i * n + k] * M[(size_t)j * n + k];
+    C[i] = c;
+    M[(size_t)i * n + j] = c / ljj;
+    M[(size_t)j * n + i] = 0;
+    if (M[(size_t)i * n + j] > beta) over = 1; /* :641 compares without fabs */
+  }
+  if (over) {
+    double theta = 0;
+    for (int i = j + 1; i < n; i++) theta = fmax(theta, fabs(C[i]));
+    ljj = theta / beta; /* :673-674 */
+    M[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; i++) M[(size_t)i * n + j] = C[i] / ljj;
+  }
+}
+
+void orc_cholmod(int n, const double *A, double *L, double *E) {
+  double delta, beta;
+  orc_get_delta_beta(n, A, &delta, &beta);
+  memcpy(L, A, sizeof(double) * (size_t)n * n);
+  double *C = (double *)xmalloc(sizeof(double) * (size_t)n);
+  double *bak = (double *)xmalloc(sizeof(double) * 3 * (size_t)n);
+  for (int J = 0; J + 3 <= n; J += 3) {
+    /* block column J as a plain 3-column Cholesky step (cholmod_blk.cl:87-268, :276-420) */
+    for (int r = J; r < n; r++)
+      for (int c = 0; c < 3; c++) bak[3 * (size_t)r + c] = L[(size_t)r * n + J + c];
+    int fail = 0;
+    double T[3][3];
+    for (int u = 0; u < 3; u++)
+      for (int v = 0; v < 3; v++) {
+        double t = L[(size_t)(J + u) * n + J + v];
+        for (int k = 0; k < J; k++) t -= L[(size_t)(J + u) * n + k] * L[(size_t)(J + v) * n + k];
+        T[u][v] = t;
+      }
+    double l00 = T[0][0], l10 = 0, l11 = 0, l20 = 0, l21 = 0, l22 = 0;
+    if (!isfinite(l00) || l00 <= 0) fail = 1;
+    if (!fail) {
+      l00 = sqrt(l00);
+      l10 = T[1][0] / l00;
+      l20 = T[2][0] / l00;
+      l11 = T[1][1] - l10 * l10;
+      if (!isfinite(l11) || l11 <= 0) fail = 1;
+    }
+    if (!fail) {
+      l11 = sqrt(l11);
+      l21 = (T[2][1] - l20 * l10) / l11;
+      l22 = T[2][2] - l20 * l20 - l21 * l21;
+      if (!isfinite(l22) || l22 <= 0 || !isfinite(l10) || !isfinite(l20) || !isfinite(l21)) fail = 1;
+    }
+    if (!fail) {
+      l22 = sqrt(l22);
+      /* L_iJ = T_iJ L_JJ^-T for the rows below; an entry above beta sends the block column to the
+       * one-column route (:352-354, compared without fabs) */
+      L[(size_t)J * n + J] = l00;
+      L[(size_t)(J + 1) * n + J] = l10; L[(size_t)(J + 1) * n + J + 1] = l11;
+      L[(size_t)(J + 2) * n + J] = l20; L[(size_t)(J + 2) * n + J + 1] = l21; L[(size_t)(J + 2) * n + J + 2] = l22;
+      L[(size_t)J * n + J + 1] = L[(size_t)J * n + J + 2] = L[(size_t)(J + 1) * n + J + 2] = 0;
+      for (int i = J + 3; i < n && !fail; i++) {
+        double t[3];
+        for (int v = 0; v < 3; v++) {
+          double x = L[(size_t)i * n + J + v];
+          for (int k = 0; k < J; k++) x -= L[(size_t)i * n + k] * L[(size_t)(J + v) * n + k];
+          t[v] = x;
+        }
+        double x0 = t[0] / l00;
+        double x1 = (t[1] - x0 * l10) / l11;
+        double x2 = (t[2] - x0 * l20 - x1 * l21) / l22;
+        L[(size_t)i * n + J] = x0; L[(size_t)i * n + J + 1] = x1; L[(size_t)i * n + J + 2] = x2;
+        for (int v = 0; v < 3; v++) L[(size_t)(J + v) * n + i] = 0;
+        if (x0 > beta || x1 > beta || x2 > beta) fail = 1;
+      }
+    }
+    if (fail) { /* restore the block column and take its columns one at a time (:240-262, :436-462) */
+      for (int r = J; r < n; r++)
+        for (int c = 0; c < 3; c++) L[(size_t)r * n + J + c] = bak[3 * (size_t)r + c];
+      for (int c = 0; c < 3; c++) cholmod_single_column(n, L, J + c, beta, delta, C);
+    }
+  }
+  for (int i = 0; i < n; i++) { /* kern_cholmod_E, :830-846 */
+    double s = 0;
+    for (int k = 0; k <= i; k++) s += L[(size_t)i * n + k] * L[(size_t)i * n + k];
+    E[i] = s - A[(size_t)i * n + i];
+  }
+  free(C);
+  free(bak);
+}
+
+/* the step inside the trust region: the minimiser of the model over span{P_U, P_B} when it is
+ * short enough, else the dog-leg path (trust_region.cpp:520-595, compute_p_2) */
+static double tr_step(int n, double uBu, double uBb, double bBb, double delta, const double *PU,
+                      const double *PB, double *p, const double *g) {
+  const double ug = dot_n(n, PU, g), bg = dot_n(n, PB, g);
+  const double det = -uBb * uBb + bBb * uBu;
+  const double eta1 = (bg * uBb) / det - (bBb * ug) / det;
+  const double eta2 = (ug * uBb) / det - (bg * uBu) / det;
+  double nrm = 0;
+  for (int i = 0; i < n; i++) {
+    p[i] = eta1 * PU[i] + eta2 * PB[i];
+    nrm += p[i] * p[i];
+  }
+  nrm = sqrt(nrm);
+  if (!(nrm > delta)) return nrm;
+  double nu = 0, nb = 0;
+  for (int i = 0; i < n; i++) {
+    nu += PU[i] * PU[i];
+    nb += PB[i] * PB[i];
+  }
+  nu = sqrt(nu);
+  nb = sqrt(nb);
+  if (nu > delta) {
+    for (int i = 0; i < n; i++) p[i] = delta * PU[i] / nu;
+    return delta;
+  }
+  if (nb <= delta) { /* (the reference returns sqrt(nrm + nb^2) here, a value only printed) */
+    for (int i = 0; i < n; i++) p[i] = PB[i];
+    return nb;
+  }
+  double a = 0, b = 0, c = 0;
+  for (int i = 0; i < n; i++) {
+    const double Ai = PB[i] - PU[i], Bi = 2 * PU[i] - PB[i];
+    a += Ai * Ai;
+    b += Ai * Bi;
+    c += Bi * Bi;
+  }
+  b = 2 * b;
+  c = c - delta * delta;
+  double disc = b * b - 4 * a * c;
+  if (fabs(disc) < 1e-12) disc = 0;
+  const double tau = (-b + sqrt(disc)) / (2 * a);
+  for (int i = 0; i < n; i++) p[i] = PU[i] + (tau - 1) * (PB[i] - PU[i]);
+  return delta;
+}
+
+int orc_trust_region(int nC, int nP, int nO, const double *K, const double *impts,
+                     const double *initrot, double *cams, double *pts, const int *iidx,
+                     const int *jidx, const orc_tr_opts *opts, orc_tr_result *res, double *log) {
+  const int nA = 6 * nC, nB = 3 * nP, nT = nA + nB;
+  const double EPS2 = 1e-12, MAX_DELTA = 10000; /* psba.h:9, trust_region.cpp:18 */
+  double *ex = xmalloc(sizeof(double) * 2 * (size_t)nO);
+  double *JA = xmalloc(sizeof(double) * 12 * (size_t)nO);
+  double *JB = xmalloc(sizeof(double) * 6 * (size_t)nO);
+  double *W = xmalloc(sizeof(double) * 18 * (size_t)nO);
+  double *Y = xmalloc(sizeof(double) * 18 * (size_t)nO);
+  double *U = xmalloc(sizeof(double) * 36 * (size_t)nC);
+  double *V = xmalloc(sizeof(double) * 9 * (size_t)nP);
+  double *Vinv = xmalloc(sizeof(double) * 9 * (size_t)nP);
+  double *UVdiag = xmalloc(sizeof(double) * (size_t)nT);
+  double *S = xmalloc(sizeof(double) * (size_t)nA * nA);
+  double *Sf = xmalloc(sizeof(double) * (size_t)nA * nA);
+  double *g = xmalloc(sizeof(double) * (size_t)nT);
+  double *eab = xmalloc(sizeof(double) * (size_t)nT);
+  double *PU = xmalloc(sizeof(double) * (size_t)nT);
+  double *PB = xmalloc(sizeof(double) * (size_t)nT);
+  double *P = xmalloc(sizeof(double) * (size_t)nT);
+  double *Jx1 = xmalloc(sizeof(double) * 2 * (size_t)nO);
+  double *Jx2 = xmalloc(sizeof(double) * 2 * (size_t)nO);
+  double *newcams = xmalloc(sizeof(double) * (size_t)nA);
+  double *newpts = xmalloc(sizeof(double) * (size_t)nB);
+  double *exn = xmalloc(sizeof(double) * 2 * (size_t)nO);
+  memset(res, 0, sizeof(*res));
+  double dk = 1, lambda = 0, origin_lambda = 0; /* :95-96 */
+  int nu = 2, notgood = 0, good_iters = 0, itno = opts->start_itno, nlog = 0, tries = 0;
+  int flag = ORC_ITER_CONTINUE;
+
+  orc_compute_exQT(nO, K, impts, initrot, cams, pts, iidx, jidx, ex); /* :106-107 */
+  double ex_L2 = orc_L2_sq(2 * nO, ex);
+  res->init_err = ex_L2;
+  double final_err = ex_L2;
+
+  for (; itno < opts->max_iter; itno++) { /* :112 */
+    orc_compute_jacobiQT(nO, K, initrot, cams, pts, iidx, jidx, JA, JB); /* :117 */
+    orc_compute_g(nC, nP, nO, -2.0, JA, JB, iidx, jidx, ex, g);          /* :122, g = grad ||e||^2 */
+    orc_compute_Jmultiply(nC, nO, JA, JB, iidx, jidx, g, Jx1);           /* :125 */
+    const double gtBg = 2 * dot_n(2 * nO, Jx1, Jx1), gtg = dot_n(nT, g, g);
+    for (int i = 0; i < nT; i++) PU[i] = -(g[i] * gtg) / gtBg;           /* :128-130 Cauchy step */
+    orc_compute_U(nC, nO, JA, jidx, 2.0, U, UVdiag);                     /* :133-137 */
+    orc_compute_V(nC, nP, nO, JB, iidx, 2.0, V, UVdiag);
+    orc_compute_Wblks(nO, JA, JB, 2.0, W);
+    int solved = 0;
+    while (!solved) { /* :141-163 around compute_PB (:292-405) */
+      orc_update_UV(nC, nP, U, V, lambda);
+      orc_compute_Vinv(nP, V, Vinv);
+      orc_compute_Yblks(nO, iidx, W, Vinv, Y);
+      orc_compute_S(nC, nP, nO, iidx, jidx, U, Y, W, S);
+      memcpy(Sf, S, sizeof(double) * (size_t)nA * nA); /* :332-334 backup, the factorization overwrites */
+      orc_compute_ea(nC, nP, nO, iidx, jidx, Y, g, eab);
+      double ret = orc_chol_solve(nA, Sf, eab, P);
+      if (ret != 0.0) {
+        res->chol_fail++;
+        if (lambda == 0.0) { /* :341-363: lambda from the diagonal correction of a modified Cholesky */
+          double *E = xmalloc(sizeof(double) * (size_t)nA);
+          orc_cholmod(nA, S, Sf, E);
+          double sum = 0;
+          for (int i = 0; i < nA; i++) sum += E[i];
+          lambda = fabs(sum) / nA;
+          free(E);
+        } else {
+          lambda = 2 * lambda; /* :365-368 */
+        }
+        if (origin_lambda != 0.0) { /* :144-155 */
+          if (nu > 4) {
+            flag = ORC_ITER_TURN_TO_LM;
+            final_err = ex_L2;
+            goto done;
+          }
+          lambda = lambda * nu;
+          nu = nu * 2;
+        }
+        orc_restore_UVdiag(nC, nP, U, V, UVdiag);
+        if (!isfinite(lambda) || res->chol_fail > 200) { /* (guard: the reference would spin) */
+          flag = ORC_ITER_ERR;
+          goto done;
+        }
+        continue;
+      }
+      orc_compute_eb(nC, nP, nO, iidx, jidx, W, P, g, eab); /* :385-391 */
+      orc_compute_dpb(nC, nP, Vinv, eab, P);
+      for (int i = 0; i < nT; i++) PB[i] = -P[i];            /* :394-395 */
+      orc_restore_UVdiag(nC, nP, U, V, UVdiag);              /* (U, V reused by the next lambda) */
+      solved = 1;
+      nu = 2;
+      origin_lambda = lambda; /* :158-161 */
+    }
+    orc_compute_Jmultiply(nC, nO, JA, JB, iidx, jidx, PU, Jx1); /* :166-176 */
+    orc_compute_Jmultiply(nC, nO, JA, JB, iidx, jidx, PB, Jx2);
+    const double uBu = 2 * dot_n(2 * nO, Jx1, Jx1), uBb = 2 * dot_n(2 * nO, Jx1, Jx2),
+                 bBb = 2 * dot_n(2 * nO, Jx2, Jx2);
+    flag = ORC_ITER_CONTINUE;
+    while (flag == ORC_ITER_CONTINUE) { /* :180-277 */
+      tries++;
+      const double p_norm = tr_step(nT, uBu, uBb, bBb, dk, PU, PB, P, g);
+      orc_compute_newp(nA, nB, cams, pts, P, newcams, newpts);
+      orc_compute_exQT(nO, K, impts, initrot, newcams, newpts, iidx, jidx, exn);
+      const double act = orc_L2_sq(2 * nO, exn);
+      if (fabs((ex_L2 - act) / ex_L2) < EPS2) { /* :197-202 */
+        flag = ORC_ITER_DP_NO_CHANGE;
+        break;
+      }
+      orc_compute_Jmultiply(nC, nO, JA, JB, iidx, jidx, P, Jx1); /* :209-213 */
+      const double Jx_norm = 2 * orc_L2_sq(2 * nO, Jx1);
+      const double pred = dot_n(nT, g, P) + ex_L2 + Jx_norm / 2;
+      const double rho = (ex_L2 - act) / (ex_L2 - pred); /* :221-222 */
+      int accepted = 0;
+      if (rho < 0.25 || act > ex_L2) {
+        dk = dk / 4;
+      } else if (rho >= 0.75 && act < ex_L2) {
+        accepted = 1;
+        dk = fmin(2 * dk, MAX_DELTA);
+      } else if (rho >= 0.25 && rho < 0.75 && act < ex_L2) {
+        accepted = 1;
+      } else if (isnan(rho)) {
+        flag = ORC_ITER_TURN_TO_LM;
+        final_err = ex_L2;
+        goto done;
+      }
+      if (accepted) { /* update_p, :233-234,:244-245 */
+        flag = 7; /* ITER_PASS */
+        memcpy(cams, newcams, sizeof(double) * (size_t)nA);
+        memcpy(pts, newpts, sizeof(double) * (size_t)nB);
+        memcpy(ex, exn, sizeof(double) * 2 * (size_t)nO); /* residual at the new current parameters */
+        final_err = act;
+      }
+      if (opts->verbose)
+        printf("itno=%d\tErr:%.15E\tDelta=%f\tRho=%f\tnorm_p=%f\tLambda=%E\n", itno, act, dk, rho, p_norm, lambda);
+      if (log && nlog < opts->log_cap) {
+        double *row = log + 6 * nlog++;
+        row[0] = itno; row[1] = act; row[2] = rho; row[3] = dk; row[4] = lambda; row[5] = accepted;
+      }
+      if (fabs((act - ex_L2) / ex_L2) <= EPS2) { /* :252-255 */
+        flag = ORC_ITER_ERR_SMALL_ENOUGH;
+        break;
+      }
+      if (rho < 0.25) { /* :257-264 */
+        if (++notgood >= 5) {
+          flag = ORC_ITER_TURN_TO_LM;
+          break;
+        }
+      } else
+        notgood = 0;
+      if (rho > 0.75 && act < ex_L2) { /* :266-271 */
+        if (++good_iters >= 10) {
+          lambda = 0.0;
+          origin_lambda = 0.0;
+          good_iters = 0;
+        }
+      } else
+        good_iters = 0;
+      if (rho > 0.25 && act < ex_L2) ex_L2 = act; /* :272-275 */
+    }
+    if (flag != 7) break; /* :278-279 */
+  }
+done:
+  res->flag = flag;
+  res->iters = itno;
+  res->tries = tries;
+  res->final_err = final_err;
+  res->lambda = lambda;
+  res->delta = dk;
+  res->n_log = nlog;
+  free(ex); free(JA); free(JB); free(W); free(Y); free(U); free(V); free(Vinv); free(UVdiag); free(S); free(Sf);
+  free(g); free(eab); free(PU); free(PB); free(P); free(Jx1); free(Jx2); free(newcams); free(newpts); free(exn);
   return flag;
 }

@@ -101,6 +101,7 @@ typedef struct {
   int tr_handoff;   /* 1: return ITER_TURN_TO_TR after 5 good iterations (levmar.cpp:215-219) */
   int verbose;
   int log_cap;      /* capacity (rows) of log, 0 = no log */
+  int start_itno;   /* itno is a global shared by levmar() and trust_region() (PSBA/main.cpp:193-208) */
 } orc_lm_opts;
 
 typedef struct {
@@ -123,6 +124,49 @@ int orc_threads(void);
 int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
                const double *initrot, double *cams, double *pts, const int *iidx,
                const int *jidx, const orc_lm_opts *opts, orc_lm_result *res, double *log);
+
+/* ---- the trust-region caller and its extra operators -------------------- */
+
+/* CL_files/compute_Jmultiply.cl:6-52 (J x), stored per observation: out[2 a + k] instead of
+ * the reference's dense nP x nC x 2 grid whose unobserved entries are zero; every use is a dot
+ * product, which the zeros do not change and whose order of summation (point-major, cameras
+ * ascending) is the observation order. */
+void orc_compute_Jmultiply(int nC, int nO, const double *JA, const double *JB, const int *iidx,
+                           const int *jidx, const double *x, double *out);
+
+/* PSBA/cl_cholmod.cpp:109-168 + CL_files/cholmod_blk.cl:796-825: delta and beta of the modified
+ * Cholesky from the largest |off-diagonal| and |diagonal| entries of the n x n matrix. */
+void orc_get_delta_beta(int n, const double *A, double *delta, double *beta);
+/* PSBA/cl_cholmod.cpp:25-101,176-201 + CL_files/cholmod_blk.cl:87-846: modified Cholesky of the
+ * symmetric n x n matrix A (n a multiple of 3), block columns of three: a plain Cholesky of the
+ * block column while its pivots stay positive and its entries below beta, otherwise the three
+ * columns one by one with d_j = max(|c_jj|, delta), raised to (theta_j / beta)^2 when an entry
+ * would exceed beta.  L (n x n, lower) and E[i] = sum_k L[i][k]^2 - A[i][i] are returned. */
+void orc_cholmod(int n, const double *A, double *L, double *E);
+
+typedef struct {
+  int max_iter;     /* literal 50, shared with levmar() through itno (trust_region.cpp:112) */
+  int start_itno;
+  int verbose;
+  int log_cap;      /* rows of 6 doubles */
+} orc_tr_opts;
+
+typedef struct {
+  int flag;         /* ITER_* */
+  int iters;        /* itno at exit */
+  int tries;        /* steps evaluated (inner loop passes) */
+  int chol_fail;    /* failed factorizations of S (each followed by a larger lambda) */
+  double init_err, final_err;
+  double lambda, delta; /* at exit */
+  int n_log;
+} orc_tr_result;
+
+/* PSBA/trust_region.cpp:49-288 (trust_region), :292-405 (compute_PB), :520-595 (compute_p_2).
+ * cams/pts are updated in place.  log rows: (itno, ||e(p + step)||^2, rho, delta after the
+ * update, lambda, accepted). */
+int orc_trust_region(int nC, int nP, int nO, const double *K, const double *impts,
+                     const double *initrot, double *cams, double *pts, const int *iidx,
+                     const int *jidx, const orc_tr_opts *opts, orc_tr_result *res, double *log);
 
 #ifdef __cplusplus
 }

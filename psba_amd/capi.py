@@ -41,6 +41,21 @@ class LmResult(C.Structure):
                 ("n_log", C.c_int), ("seconds", C.c_double)]
 
 
+class TrOptions(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int)]
+
+
+class TrResult(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iters", C.c_int), ("tries", C.c_int), ("chol_fail", C.c_int),
+                ("init_err", C.c_double), ("final_err", C.c_double), ("lambda_", C.c_double),
+                ("delta", C.c_double), ("n_log", C.c_int), ("seconds", C.c_double)]
+
+
+class SolveResult(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iters", C.c_int), ("lm_calls", C.c_int), ("tr_calls", C.c_int),
+                ("init_err", C.c_double), ("final_err", C.c_double), ("seconds", C.c_double)]
+
+
 class CProblem(C.Structure):
     _fields_ = [("nCams", C.c_int), ("n3Dpts", C.c_int), ("n2Dprojs", C.c_int), ("Kparas", _dp),
                 ("impts", _dp), ("initrot", _dp), ("camsEx", _dp), ("pts3D", _dp), ("iidx", _ip),
@@ -105,6 +120,15 @@ SIGNATURES = [
     ("psba_profile_reset", C.c_int, [_h]),
     ("psba_profile_get", C.c_int, [_h, C.c_int, _dp, _ip]),
     ("psba_algorithmic_bytes", C.c_int, [_h, C.c_int, _dp]),
+    ("psba_compute_Jmultiply", C.c_int, [_h, _dp, _dp]),
+    ("psba_jmul_dots", C.c_int, [_h, _dp, _dp, _dp]),
+    ("psba_get_gradient", C.c_int, [_h, _dp]),
+    ("psba_get_dp", C.c_int, [_h, _dp]),
+    ("psba_set_step", C.c_int, [_h, _dp]),
+    ("psba_cholmod_lambda", C.c_int, [_h, C.c_int, _dp, _dp]),
+    ("psba_tr_default_options", None, [C.POINTER(TrOptions)]),
+    ("psba_trust_region", C.c_int, [_h, C.POINTER(TrOptions), C.POINTER(TrResult), _dp]),
+    ("psba_solve", C.c_int, [_h, C.c_int, C.c_int, C.POINTER(SolveResult)]),
     ("psba_write_problem", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
     ("psba_convert_bal", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dp]),
     ("psba_schur_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
@@ -399,6 +423,43 @@ class Psba:
         log = np.zeros((max(log_cap, 1), 5))
         self._ck(lib.psba_levmar(self._h, C.byref(opts), C.byref(res), _d(log)))
         return res, log[: res.n_log].copy()
+
+    # ---- trust region ----
+    def compute_Jmultiply(self, x):
+        return self._out(lambda h, out: lib.psba_compute_Jmultiply(h, _d(_c(x)), out), 2 * self.nO)[1]
+
+    def jmul_dots(self, x1, x2=None):
+        out = np.empty(3)
+        a1 = _c(x1)
+        a2 = None if x2 is None else _c(x2)
+        self._ck(lib.psba_jmul_dots(self._h, _d(a1), _d(a2), _d(out)))
+        return out
+
+    def get_gradient(self):
+        return self._out(lib.psba_get_gradient, self.nT)[1]
+
+    def get_dp(self):
+        return self._out(lib.psba_get_dp, self.nT)[1]
+
+    def set_step(self, dp):
+        self._ck(lib.psba_set_step(self._h, _d(_c(dp))))
+
+    def cholmod_lambda(self, reassemble=True):
+        lam, info = C.c_double(), np.empty(3)
+        self._ck(lib.psba_cholmod_lambda(self._h, int(reassemble), C.byref(lam), _d(info)))
+        return lam.value, info
+
+    def trust_region(self, max_iter=50, start_itno=0, verbose=False, log_cap=512):
+        opts = TrOptions(max_iter, start_itno, int(verbose), log_cap)
+        res = TrResult()
+        log = np.zeros((max(log_cap, 1), 6))
+        self._ck(lib.psba_trust_region(self._h, C.byref(opts), C.byref(res), _d(log)))
+        return res, log[: res.n_log].copy()
+
+    def solve(self, max_iter=50, verbose=False):
+        res = SolveResult()
+        self._ck(lib.psba_solve(self._h, max_iter, int(verbose), C.byref(res)))
+        return res
 
     # ---- multi-GPU ----
     @staticmethod

@@ -123,6 +123,9 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->redp);
   dev_free(h->slab);
   dev_free(h->dp);
+  dev_free(h->trv[0]);
+  dev_free(h->trv[1]);
+  dev_free(h->jmul_out);
   dev_free(h->chol_ws);
   dev_free(h->chol_L);
   dev_free(h->dbg_ex);
@@ -597,6 +600,88 @@ int psba_accept(psba_handle h) {
     h->lin_is_ahead = true;
   }
   h->ahead = false;
+  return PSBA_OK;
+}
+
+// ---- operators of the trust-region caller ---------------------------------
+
+static int d2h(psba_ctx *h, void *dst, const void *src, size_t bytes);
+
+static int ensure_trv(psba_ctx *h) {
+  for (int k = 0; k < 2; k++)
+    if (!h->trv[k]) TRY(dev_alloc(h, &h->trv[k], (size_t)h->d.nT));
+  return PSBA_OK;
+}
+
+int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dots[3]) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (!x1 || !dots) return fail(h, PSBA_E_INVALID, "psba_jmul_dots: null pointer");
+  if (h->nranks > 1) return fail(h, PSBA_E_INVALID, "the trust-region operators are single-rank");
+  TRY(ensure_trv(h));
+  const size_t bytes = sizeof(double) * (size_t)h->d.nT;
+  PSBA_HIP(h, hipMemcpyAsync(h->trv[0], x1, bytes, hipMemcpyHostToDevice, h->stream));
+  if (x2 && x2 != x1) PSBA_HIP(h, hipMemcpyAsync(h->trv[1], x2, bytes, hipMemcpyHostToDevice, h->stream));
+  TRY(launch_jmul(h, h->trv[0], (x2 && x2 != x1) ? h->trv[1] : h->trv[0], nullptr, h->scal + SC_TR_DOTS));
+  TRY(fetch_scalars(h));
+  for (int k = 0; k < 3; k++) dots[k] = h->h_scal[SC_TR_DOTS + k];
+  return PSBA_OK;
+}
+
+int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (!x) return fail(h, PSBA_E_INVALID, "psba_compute_Jmultiply: null pointer");
+  TRY(ensure_trv(h));
+  if (!h->jmul_out) TRY(dev_alloc(h, &h->jmul_out, (size_t)2 * h->d.nO));
+  PSBA_HIP(h, hipMemcpyAsync(h->trv[0], x, sizeof(double) * (size_t)h->d.nT, hipMemcpyHostToDevice, h->stream));
+  TRY(launch_jmul(h, h->trv[0], h->trv[0], h->jmul_out, h->scal + SC_TR_DOTS));
+  return d2h(h, Jmul, h->jmul_out, sizeof(double) * 2 * (size_t)h->d.nO);
+}
+
+int psba_get_gradient(psba_handle h, double *g) {
+  CHECK_H(h);
+  NEED(h, h->linearized, "psba_linearize first");
+  if (!g) return PSBA_E_INVALID;
+  TRY(ensure_trv(h));
+  TRY(launch_pack_g(h, h->trv[0]));
+  return d2h(h, g, h->trv[0], sizeof(double) * (size_t)h->d.nT);
+}
+
+int psba_get_dp(psba_handle h, double *dp) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  return d2h(h, dp, h->dp, sizeof(double) * (size_t)h->d.nT);
+}
+
+int psba_set_step(psba_handle h, const double *dp) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (!dp) return PSBA_E_INVALID;
+  PSBA_HIP(h, hipMemcpyAsync(h->dp, dp, sizeof(double) * (size_t)h->d.nT, hipMemcpyHostToDevice, h->stream));
+  TRY(launch_newp(h, h->dp));
+  h->ahead = false;  // a linearization computed ahead belongs to another proposal
+  h->backsubbed = true;  // a proposal exists: psba_accept may take it
+  return PSBA_OK;
+}
+
+int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  if (h->nranks > 1) return fail(h, PSBA_E_INVALID, "the trust-region operators are single-rank");
+  if (reassemble) {
+    // S at lambda = 0 again (the failed factorization worked in place), then the modified
+    // Cholesky on a copy of it (trust_region.cpp:341-363)
+    NEED(h, h->linearized, "psba_linearize first");
+    TRY(launch_schur(h, 0.0, false));
+  }
+  h->diag_done = false;  // the first diagonal block's factor in chol_L is about to be overwritten
+  TRY(launch_cholmod(h, h->scal + SC_CHOLMOD));
+  TRY(fetch_scalars(h));
+  if (lambda) *lambda = h->h_scal[SC_CHOLMOD];
+  if (info3)
+    for (int k = 0; k < 3; k++) info3[k] = h->h_scal[SC_CHOLMOD + 1 + k];
+  h->assembled = h->solved = false;
   return PSBA_OK;
 }
 

@@ -31,6 +31,8 @@ enum {
   SC_PART = 16,      // K3: [SC_NPART][4] partial (dp_l2, gain_den, new_cost, newp_l2), summed on the host
   SC_STATUS_V = 80,  // K3: 1.0 when some V_i was singular in this try (summable over ranks)
   SC_STATUS_SPD = 81,  // K3: 1.0 when the Cholesky of this try failed
+  SC_TR_DOTS = 84,     // trust-region operators: (Jx1.Jx1, Jx1.Jx2, Jx2.Jx2)
+  SC_CHOLMOD = 88,     // modified Cholesky: lambda, delta, beta, block columns on the one-column route
 };
 
 struct Dims {
@@ -121,6 +123,8 @@ struct psba_ctx {
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
+  double *trv[2] = {nullptr, nullptr};  // [nT] each: vectors of the trust-region operators (allocated on first use)
+  double *jmul_out = nullptr;   // [2 nO] J x of psba_compute_Jmultiply (allocated on first use)
   hipGraphExec_t chol_graph[2] = {nullptr, nullptr};  // captured panel chain of kernels_chol_graph.hip, with / without its first step
   int chol_graph_n32[2] = {0, 0};
   double *chol_graph_red[2] = {nullptr, nullptr};
@@ -194,5 +198,10 @@ int launch_chol_solve(psba_ctx *h);
 int launch_chol_graph(psba_ctx *h);
 // kernels_backsub.hip
 int launch_backsub(psba_ctx *h, double mu, bool dump);
+// kernels_tr.hip
+int launch_jmul(psba_ctx *h, const double *x1_dev, const double *x2_dev, double *out1_dev, double *dots_dev);
+int launch_pack_g(psba_ctx *h, double *g_dev);
+int launch_newp(psba_ctx *h, const double *dp_dev);
+int launch_cholmod(psba_ctx *h, double *out4_dev);
 
 }  // namespace psba

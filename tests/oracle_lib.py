@@ -12,7 +12,8 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
 class LmOpts(C.Structure):
-    _fields_ = [("max_iter", C.c_int), ("tr_handoff", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int)]
+    _fields_ = [("max_iter", C.c_int), ("tr_handoff", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int),
+                ("start_itno", C.c_int)]
 
 
 class LmResult(C.Structure):
@@ -127,13 +128,70 @@ class Oracle:
         _dpb(self.nC, self.nP, sch["Vinv"], eab, dp)
         return ret, dp, eab
 
-    def levmar(self, max_iter=50, tr_handoff=False, log_cap=512, verbose=False):
-        opts = LmOpts(max_iter, int(tr_handoff), int(verbose), log_cap)
+    def levmar(self, max_iter=50, tr_handoff=False, log_cap=512, verbose=False, start_itno=0):
+        opts = LmOpts(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno)
         res = LmResult()
         log = np.zeros((max(log_cap, 1), 5))
         _lm(self.nC, self.nP, self.nO, self.K, self.impts, self.initrot, self.cams, self.pts, self.iidx,
             self.jidx, C.byref(opts), C.byref(res), log.ctypes.data_as(C.c_void_p))
         return res, log[: res.n_log].copy()
+
+
+class TrOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int)]
+
+
+class TrResult(C.Structure):
+    _fields_ = [("flag", C.c_int), ("iters", C.c_int), ("tries", C.c_int), ("chol_fail", C.c_int),
+                ("init_err", C.c_double), ("final_err", C.c_double), ("lambda_", C.c_double),
+                ("delta", C.c_double), ("n_log", C.c_int)]
+
+
+_tr = _sig("orc_trust_region", _i, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.POINTER(TrOpts),
+           C.POINTER(TrResult), C.c_void_p)
+_jmul = _sig("orc_compute_Jmultiply", None, _i, _i, _dp, _dp, _ip, _ip, _dp, _dp)
+_cholmod = _sig("orc_cholmod", None, _i, _dp, _dp, _dp)
+_delta_beta = _sig("orc_get_delta_beta", None, _i, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def cholmod(A):
+    """orc_cholmod: (L, E, delta, beta) of the symmetric matrix A."""
+    A = _c(A)
+    n = A.shape[0]
+    L, E = np.empty((n, n)), np.empty(n)
+    d, b = C.c_double(), C.c_double()
+    _delta_beta(n, A.reshape(-1), C.byref(d), C.byref(b))
+    _cholmod(n, A.reshape(-1), L.reshape(-1), E)
+    return L, E, d.value, b.value
+
+
+def trust_region(o, max_iter=50, start_itno=0, log_cap=512, verbose=False):
+    """orc_trust_region on the Oracle instance o (its cams / pts are updated in place)."""
+    opts = TrOpts(max_iter, start_itno, int(verbose), log_cap)
+    res = TrResult()
+    log = np.zeros((max(log_cap, 1), 6))
+    _tr(o.nC, o.nP, o.nO, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, C.byref(opts), C.byref(res),
+        log.ctypes.data_as(C.c_void_p))
+    return res, log[: res.n_log].copy()
+
+
+def solve_like_main(o, max_total=50):
+    """The reference driver's alternation (PSBA/main.cpp:193-208): levmar() until it hands over
+    (ITER_TURN_TO_TR), trust_region() until it hands back (ITER_TURN_TO_LM), sharing itno.
+    Returns the list of (which, result) in order."""
+    out, itno = [], 0
+    while True:
+        res, _ = o.levmar(max_iter=max_total, tr_handoff=True, start_itno=itno)
+        out.append(("lm", res))
+        itno = res.iters
+        if res.flag != 2:
+            break
+        res, _ = trust_region(o, max_iter=max_total, start_itno=itno)
+        out.append(("tr", res))
+        itno = res.iters
+        if res.flag != 1:
+            break
+    return out
 
 
 _SO_OMP = os.path.join(_ROOT, "oracle", "libpsba_oracle_omp.so")
@@ -158,7 +216,7 @@ def levmar_all_cores(prob, max_iter=10, tr_handoff=False):
     f.argtypes = _lm.argtypes
     lib.orc_threads.restype = C.c_int
     o = Oracle(prob)
-    opts = LmOpts(max_iter, int(tr_handoff), 0, 0)
+    opts = LmOpts(max_iter, int(tr_handoff), 0, 0, 0)
     res = LmResult()
     log = np.zeros((1, 5))
     f(o.nC, o.nP, o.nO, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, C.byref(opts), C.byref(res),
