@@ -550,6 +550,101 @@ __global__ __launch_bounds__(256) void k_schur_finalize(double *S, double *ea, c
   write_padding(S, nA, n32, pad_one, gtid, gsize);
 }
 
+// ---- owner route: many cameras -----------------------------------------------------------
+// One thread per unit (block (j, k) of the lower block triangle x a segment of its product list,
+// see OwnerPlanHost in psba_internal.h).  The thread walks its products (a, b): V*^-1 and
+// Y_a = W_a V*^-1 in registers, acc -= Y_a W_b^T; a diagonal block's unit also sums
+// e_a -= Y_a g_b,i.  No scatter: the 36 sums stay in registers and leave once -- plain stores when
+// the unit is the block's only one, fp64 atomic adds into the zeroed S otherwise.  The reference
+// gathers the same products per output scalar through comm3DIdx (CL_files/compute_S.cl:24-52).
+struct SchurOwnerArgs {
+  const double *W, *PV;
+  const int *iidx;
+  const int2 *prod;
+  const OwnerWave *waves;
+  const OwnerUnit *units;
+  double *S, *ea;
+  int *status;
+  double mu;
+  int nWaves, ld, try_id;
+};
+
+__global__ __launch_bounds__(256) void k_schur_owner(SchurOwnerArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= p.nWaves) return;
+  const OwnerWave wv = p.waves[w];
+  const OwnerUnit un = p.units[(size_t)w * 64 + lane];
+  const bool diag = un.j == un.k;
+  double acc[36], ea[6];
+#pragma unroll
+  for (int t = 0; t < 36; t++) acc[t] = 0.0;
+#pragma unroll
+  for (int t = 0; t < 6; t++) ea[t] = 0.0;
+  const int2 *pr = p.prod + (size_t)wv.row0 * 64 + lane;
+  int2 ab = wv.len > 0 ? pr[0] : make_int2(-1, -1);
+  for (int t = 0; t < wv.len; t++) {
+    const int2 nxt = t + 1 < wv.len ? pr[(size_t)(t + 1) * 64] : make_int2(-1, -1);
+    if (ab.x >= 0) {
+      const int i = p.iidx[ab.x];
+      const double *pv = p.PV + 9 * (size_t)i;
+      const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)ab.x);
+      const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)ab.y);
+      double v[6], vi[6], wr[18], wb[18];
+#pragma unroll
+      for (int q = 0; q < 6; q++) v[q] = pv[q];
+      const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const double2 x = wa[q], y = wb2[q];
+        wr[2 * q] = x.x;
+        wr[2 * q + 1] = x.y;
+        wb[2 * q] = y.x;
+        wb[2 * q + 1] = y.y;
+      }
+      v[0] += p.mu;
+      v[3] += p.mu;
+      v[5] += p.mu;
+      if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
+      double Y[18];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double w0 = wr[3 * r], w1 = wr[3 * r + 1], w2 = wr[3 * r + 2];
+        Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+        Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+        Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+      }
+      if (diag) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) ea[r] -= Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+          acc[6 * r + c] -= Y[3 * r] * wb[3 * c] + Y[3 * r + 1] * wb[3 * c + 1] + Y[3 * r + 2] * wb[3 * c + 2];
+    }
+    ab = nxt;
+  }
+  if (un.pad) return;  // idle lane of the last wave
+  double *Sb = p.S + (size_t)(6 * un.j) * p.ld + 6 * un.k;
+  if (un.multi) {
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) atomicAdd(&Sb[(size_t)r * p.ld + c], acc[6 * r + c]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) Sb[(size_t)r * p.ld + c] = acc[6 * r + c];
+  }
+  if (diag) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) atomicAdd(&p.ea[6 * un.j + r], ea[r]);
+  }
+}
+
 static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   const Dims &d = h->d;
   SchurLdsArgs a;
@@ -684,6 +779,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   a.nTiles = d.nTiles;
   a.try_id = h->try_id;
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 1) * h->n32, h->stream));
+  const bool owner = h->own_nwaves > 0 && !dump && !getenv("PSBA_SCHUR_ATOMIC");
   int grid = d.nTiles < 2048 ? d.nTiles : 2048;
   const size_t lds = sizeof(double) * (size_t)d.nA;  // e_a accumulators of the workgroup
   if (lds > 100 * 1024)
@@ -704,7 +800,23 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
     ProfScope pp(h, pair ? PSBA_K_SCHUR : -1);
     {
       ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR);
-      if (dump)
+      if (owner) {
+        SchurOwnerArgs o;
+        o.W = h->W;
+        o.PV = h->PV;
+        o.iidx = h->iidx;
+        o.prod = h->own_prod;
+        o.waves = h->own_waves;
+        o.units = h->own_units;
+        o.S = a.S;
+        o.ea = a.ea;
+        o.status = h->status;
+        o.mu = mu;
+        o.nWaves = h->own_nwaves;
+        o.ld = h->n32;
+        o.try_id = h->try_id;
+        hipLaunchKernelGGL(k_schur_owner, dim3((h->own_nwaves + 3) / 4), dim3(256), 0, h->stream, o);
+      } else if (dump)
         hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
       else
         hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);

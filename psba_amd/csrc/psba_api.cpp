@@ -122,6 +122,10 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->diag0);
   dev_free(h->redp);
   dev_free(h->slab);
+  dev_free(h->own_prod);
+  dev_free(h->own_waves);
+  dev_free(h->own_units);
+  h->own_nwaves = 0;
   dev_free(h->dp);
   dev_free(h->trv[0]);
   dev_free(h->trv[1]);
@@ -193,7 +197,7 @@ int psba_destroy(psba_handle h) {
 int psba_schur_path(psba_handle h, int *path) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  if (path) *path = (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) ? 0 : 1;
+  if (path) *path = getenv("PSBA_SCHUR_ATOMIC") ? 2 : h->nGroups > 0 ? 0 : 1;
   return PSBA_OK;
 }
 
@@ -324,10 +328,22 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
                 h->nGroups, h->nWg, plan.real_items, plan.items.size(),
                 plan.items.size() ? (double)plan.real_items / (double)plan.items.size() : 1.0,
                 8e-6 * (double)plan.slab_doubles);
-    } else if (!getenv("PSBA_QUIET")) {
-      // no silent cliff: say which route K2 takes (psba_schur_path returns the same)
-      fprintf(stderr, "[psba] K2: the lower block triangle of S (%d cameras) does not split into <= %d "
-              "LDS-sized camera-row groups; using the global-atomic assembly kernel\n", nCams, MAX_GROUPS);
+    } else {
+      // many cameras: the owner route (one thread per block segment, sums in registers)
+      OwnerPlanHost op;
+      TRY(build_owner_plan(nCams, n2Dprojs, iidx, jidx, ptr.data(), op));
+      TRY(dev_alloc(h, &h->own_prod, op.prod.size()));
+      TRY(dev_alloc(h, &h->own_waves, op.waves.size()));
+      TRY(dev_alloc(h, &h->own_units, op.units.size()));
+      PSBA_HIP(h, hipMemcpy(h->own_prod, op.prod.data(), sizeof(int2) * op.prod.size(), hipMemcpyHostToDevice));
+      PSBA_HIP(h, hipMemcpy(h->own_waves, op.waves.data(), sizeof(OwnerWave) * op.waves.size(), hipMemcpyHostToDevice));
+      PSBA_HIP(h, hipMemcpy(h->own_units, op.units.data(), sizeof(OwnerUnit) * op.units.size(), hipMemcpyHostToDevice));
+      h->own_nwaves = (int)op.waves.size();
+      h->own_products = op.products;
+      if (getenv("PSBA_SCHUR_PLAN_INFO"))
+        // no silent cliff: say which route K2 takes (psba_schur_path returns the same)
+        fprintf(stderr, "[psba] K2 owner route (%d cameras): %lld products in %zu ELL slots (fill %.3f), %d waves\n",
+                nCams, op.products, op.prod.size(), (double)op.products / (double)op.prod.size(), h->own_nwaves);
     }
   }
   auto H2D = [&](void *dst, const void *src, size_t bytes) {

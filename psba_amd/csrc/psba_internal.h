@@ -50,6 +50,28 @@ struct SchurWg {
   unsigned long long slab_off;  // where this workgroup's partition goes in psba_ctx::slab
 };
 constexpr unsigned long long SCHUR_NULL_ITEM = ~0ull;
+
+// K2's route for many cameras (no LDS partition can hold a useful part of S): one thread per
+// unit = (block of the lower block triangle, a segment of that block's product list); the
+// thread accumulates its 6x6 (and, for a diagonal block, e_a) in registers.  Units are sorted
+// by length; the 64 units of a wave read their products from an ELL-style table
+// prod[(row0 + t) * 64 + lane] (-1 padded), so the list loads are coalesced.
+struct OwnerWave {
+  long long row0;  // first ELL row of this wave
+  int len;         // rows (= longest unit of the wave)
+  int pad;
+};
+struct OwnerUnit {
+  int j, k;        // block (j, k), k <= j
+  int multi;       // 1: the block has several units -> atomic adds into the zeroed S; 0: plain stores
+  int pad;
+};
+struct OwnerPlanHost {
+  std::vector<int2> prod;          // (a, b) observation indices; a = -1: padding
+  std::vector<OwnerWave> waves;
+  std::vector<OwnerUnit> units;    // 64 per wave
+  long long products = 0;
+};
 struct SchurPlanHost {
   std::vector<unsigned long long> items;
   std::vector<SchurWg> wgs;
@@ -122,6 +144,12 @@ struct psba_ctx {
   int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
+  // K2 owner route (many cameras): see OwnerPlanHost
+  int2 *own_prod = nullptr;
+  psba::OwnerWave *own_waves = nullptr;
+  psba::OwnerUnit *own_units = nullptr;
+  int own_nwaves = 0;
+  long long own_products = 0;
   double *dp = nullptr;         // [nT] dpa | dpb                     (dp_buffer)
   double *trv[2] = {nullptr, nullptr};  // [nT] each: vectors of the trust-region operators (allocated on first use)
   double *jmul_out = nullptr;   // [2 nO] J x of psba_compute_Jmultiply (allocated on first use)
@@ -190,6 +218,7 @@ int launch_max_diag(psba_ctx *h);
 // kernels_schur.hip
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
                      const int *ptr, SchurPlanHost &out);
+int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out);
 int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip

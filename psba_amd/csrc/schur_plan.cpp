@@ -225,4 +225,66 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   return PSBA_OK;
 }
 
+// ---- owner route (many cameras) -------------------------------------------------------------
+// Products (a, b), b <= a in the same point, are bucketed by target block (counting sort, so a
+// block's list stays point-major); lists longer than LMAX are cut into segments (units); units
+// are sorted by length (longest first) and dealt 64 to a wave; a wave's products go into
+// ELL rows [t][lane].  LMAX aims at >= 256 k units so that every SIMD has several waves, but not
+// below 16 products per unit (shorter units would only multiply the atomic adds of the combine).
+int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out) {
+  const long long nBlk = tri(nCams);
+  std::vector<long long> cnt((size_t)nBlk + 1, 0);
+  long long total = 0;
+  for (int a = 0; a < nObs; a++) {
+    const long long base = tri(jidx[a]);
+    for (int b = ptr[iidx[a]]; b <= a; b++) cnt[(size_t)(base + jidx[b]) + 1]++;
+    total += a - ptr[iidx[a]] + 1;
+  }
+  for (long long t = 0; t < nBlk; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+  std::vector<int2> sorted((size_t)total);
+  {
+    std::vector<long long> at(cnt.begin(), cnt.end() - 1);
+    for (int a = 0; a < nObs; a++) {
+      const long long base = tri(jidx[a]);
+      for (int b = ptr[iidx[a]]; b <= a; b++) sorted[(size_t)at[(size_t)(base + jidx[b])]++] = make_int2(a, b);
+    }
+  }
+  long long LMAX = (total + 262143) / 262144;
+  if (LMAX < 16) LMAX = 16;
+  if (const char *e = getenv("PSBA_OWNER_LMAX")) LMAX = atoll(e) > 0 ? atoll(e) : LMAX;
+  struct Unit { long long first; int len, j, k, multi; };
+  std::vector<Unit> units;
+  units.reserve((size_t)(total / LMAX + nBlk));
+  for (int j = 0; j < nCams; j++)
+    for (int k = 0; k <= j; k++) {
+      const long long blk = tri(j) + k, n = cnt[(size_t)blk + 1] - cnt[(size_t)blk];
+      if (n == 0) continue;
+      const long long pieces = (n + LMAX - 1) / LMAX;
+      for (long long q = 0; q < pieces; q++) {
+        const long long f = n * q / pieces, l = n * (q + 1) / pieces;
+        units.push_back({cnt[(size_t)blk] + f, (int)(l - f), j, k, pieces > 1 ? 1 : 0});
+      }
+    }
+  std::stable_sort(units.begin(), units.end(), [](const Unit &x, const Unit &y) { return x.len > y.len; });
+  const size_t nW = (units.size() + 63) / 64;
+  out.waves.resize(nW);
+  out.units.assign(nW * 64, OwnerUnit{0, 0, 0, 0});
+  long long rows = 0;
+  for (size_t w = 0; w < nW; w++) {
+    const int len = units[w * 64].len;  // sorted: the first unit of a wave is its longest
+    out.waves[w] = {rows, len, 0};
+    rows += len;
+  }
+  out.prod.assign((size_t)rows * 64, make_int2(-1, -1));
+  for (size_t u = 0; u < units.size(); u++) {
+    const size_t w = u / 64, lane = u % 64;
+    out.units[u] = {units[u].j, units[u].k, units[u].multi, 0};
+    int2 *dst = out.prod.data() + (size_t)out.waves[w].row0 * 64 + lane;
+    for (int t = 0; t < units[u].len; t++) dst[(size_t)t * 64] = sorted[(size_t)(units[u].first + t)];
+  }
+  for (size_t u = units.size(); u < nW * 64; u++) out.units[u] = {0, 0, 1, 1};  // idle lanes (pad = 1)
+  out.products = total;
+  return PSBA_OK;
+}
+
 }  // namespace psba

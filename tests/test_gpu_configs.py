@@ -200,6 +200,15 @@ def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global):
     ref = np.linalg.solve(sch["S"], sch["eab"][: o.nA])
     close(dpa, ref, 1e-8, "dpa")
     gpu.restore_UVdiag()
+    # the mirror verbs above dump Y / V^-1 and therefore run the first-generation atomic kernel;
+    # the fused verb runs the owner route: same S / ea through the reduce buffer
+    gpu.linearize(1.0, 1.0)
+    gpu.schur_assemble(mu)
+    n32 = (o.nA + 31) // 32 * 32
+    M = gpu.get_reduce_buffer().reshape(n32 + 1, n32)
+    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S (owner route)")
+    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea (owner route)")
+    assert np.array_equal(M[o.nA: n32, o.nA:], np.eye(n32 - o.nA))
     gpu.upload_problem(prob)
     res, log = gpu.levmar(max_iter=3, tr_handoff=False)
     acc = log[log[:, 4] > 0]
@@ -231,12 +240,19 @@ def test_cfg5_scaled_two_thousand_cameras(gpu):
     assert np.abs(S - S.T).max() <= 1e-14 * np.abs(S).max()
     rc, dpa = gpu.SPDinv_matVec()
     assert rc == 0
+    # (the mirror verbs ran the atomic kernel: they dump Y; the owner route through the fused verb)
+    gpu.restore_UVdiag()
+    gpu.linearize(1.0, 1.0)
+    gpu.schur_assemble(mu)
+    M = gpu.get_reduce_buffer().reshape(o.nA + 1, o.nA)  # 12000 is a multiple of 32: no padding
+    close(M[: o.nA], sch["S"], 1e-11, "S (owner route)")
+    close(M[o.nA], sch["eab"][: o.nA], 1e-10, "ea (owner route)")
+    del M
     r = S @ dpa - ea
     scale = np.abs(S).sum(axis=1).max() * np.abs(dpa).max() + np.abs(ea).max()  # inf-norms
     assert np.abs(r).max() <= 1e-12 * scale, np.abs(r).max() / scale
     ref = np.linalg.solve(S, ea)
     np.testing.assert_allclose(dpa, ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
-    gpu.restore_UVdiag()
     gpu.upload_problem(prob)
     res, log = gpu.levmar(max_iter=3, tr_handoff=False)
     acc = log[log[:, 4] > 0]
