@@ -228,6 +228,121 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, double *Lx, in
   store_c_tile(Lw, ld, TR, TC, li, lk, update_tile(Lw, Lx, ld, j, TR, TC, li, lk));
 }
 
+// ---- two-level blocking for large matrices -------------------------------------------------
+// With 32-column panels every panel reads and writes the whole trailing triangle once: 8 n^3 / 96
+// bytes in all (144 GB at n = 12 000), which bounds the factorization by HBM at ~16 TFLOP/s whatever
+// the MFMA code does (measured 10.5).  Large matrices therefore go in super-panels of NB = 256
+// columns: inside a super-panel the 32-column steps update only the super-panel's own remaining
+// columns (k_cholg_update_cols), and the rest of the trailing triangle is updated once per
+// super-panel with K = NB (k_cholg_update_wide: one wave per 32x32 block, 2x2 MFMA tiles) --
+// an eighth of the traffic and eight times the flops per byte.
+
+// one 16x16 tile: C[TR][TC] -= X[TR rows][J..J+KW) X[TC rows][J..J+KW)^T, X from the factor buffer
+__device__ __forceinline__ d4 update_tile_k(const double *Lw, const double *Lx, int ld, int J, int KW, int TR,
+                                            int TC, int li, int lk) {
+  d4 c = load_c_tile(Lw, ld, TR, TC, li, lk);
+  for (int kk = 0; kk < KW; kk += GB) {
+    const Row8 a = load_row8(Lx + (size_t)(16 * TR + li) * ld + J + kk + 8 * lk);
+    const Row8 b = load_row8(Lx + (size_t)(16 * TC + li) * ld + J + kk + 8 * lk);
+    c = update_mfma(c, a, b);
+  }
+  return c;
+}
+
+// the 32-column step inside a super-panel: tiles (TR, TC) with TC in [T0, TE), TR in [TC, nT)
+// (the e_a tile row nT - 1 included), K = 32 from the panel at column j.  Workgroup 0 owns the
+// three tiles of the next diagonal block and factors it (as in k_cholg_update).
+__global__ __launch_bounds__(256) void k_cholg_update_cols(double *Lw, double *Lx, int ld, int j, int nT, int TE,
+                                                           double *linv, int *status) {
+  __shared__ Factor32Lds s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T0 = (j + GB) / 16;
+  if (blockIdx.x == 0) {
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
+    if (wave < 3) {
+      const int TR = T0 + (wave > 0), TC = T0 + (wave > 1);
+      const d4 c = update_tile(Lw, Lx, ld, j, TR, TC, li, lk);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
+    }
+    __syncthreads();
+    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    return;
+  }
+  long long idx = (long long)(blockIdx.x - 1) * 4 + wave;
+  int TC = T0;
+  while (TC < TE && idx >= nT - TC) {
+    idx -= nT - TC;
+    TC++;
+  }
+  if (TC >= TE) return;
+  const int TR = TC + (int)idx;
+  if (TR <= T0 + 1 && TC <= T0 + 1) return;  // workgroup 0's three tiles (and the unused (T0, T0+1))
+  store_c_tile(Lw, ld, TR, TC, li, lk, update_tile(Lw, Lx, ld, j, TR, TC, li, lk));
+}
+
+// the super-panel's update of everything to its right: K = KW columns of X starting at J, tile
+// columns >= Tw.  Waves own 32x32 blocks (macro tiles, 2x2 MFMA tiles: each operand piece is used
+// twice) of the lower triangle in units of 32 rows, then single tiles of the e_a tile row.
+// Workgroup 0: the next diagonal block, then its factorization.
+__global__ __launch_bounds__(256) void k_cholg_update_wide(double *Lw, double *Lx, int ld, int J, int KW, int nT,
+                                                           int Tw, double *linv, int *status) {
+  __shared__ Factor32Lds s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  if (blockIdx.x == 0) {
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
+    if (wave < 3) {
+      const int TR = Tw + (wave > 0), TC = Tw + (wave > 1);
+      const d4 c = update_tile_k(Lw, Lx, ld, J, KW, TR, TC, li, lk);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s.D[16 * (TR - Tw) + lk + 4 * r][16 * (TC - Tw) + li] = c[r];
+    }
+    __syncthreads();
+    factor_next(s, Lx, ld, 16 * Tw, linv, status, tid);
+    return;
+  }
+  const long long MR = (nT - 1 - Tw) / 2;  // macro rows: 32-row blocks below / right of the super-panel
+  const long long ntri = MR * (MR + 1) / 2;
+  long long idx = (long long)(blockIdx.x - 1) * 4 + wave + 1;  // macro index 0 = workgroup 0's block
+  if (idx >= ntri) {
+    // e_a tile row
+    const long long e = idx - ntri;
+    if (e >= nT - 1 - Tw) return;
+    const int TC = Tw + (int)e;
+    store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
+    return;
+  }
+  int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+  while ((long long)m * (m + 1) / 2 > idx) m--;
+  const int mc = (int)(idx - (long long)m * (m + 1) / 2);
+  const int TR0 = Tw + 2 * m, TC0 = Tw + 2 * mc;
+  const bool dg = m == mc;  // diagonal macro tile: its upper-right 16x16 tile is not part of the triangle
+  d4 c00 = load_c_tile(Lw, ld, TR0, TC0, li, lk), c10 = load_c_tile(Lw, ld, TR0 + 1, TC0, li, lk);
+  d4 c11 = load_c_tile(Lw, ld, TR0 + 1, TC0 + 1, li, lk);
+  d4 c01 = {0, 0, 0, 0};
+  if (!dg) c01 = load_c_tile(Lw, ld, TR0, TC0 + 1, li, lk);
+  for (int kk = 0; kk < KW; kk += GB) {
+    const size_t col = (size_t)J + kk + 8 * lk;
+    const Row8 a0 = load_row8(Lx + (size_t)(16 * TR0 + li) * ld + col);
+    const Row8 a1 = load_row8(Lx + (size_t)(16 * (TR0 + 1) + li) * ld + col);
+    const Row8 b0 = load_row8(Lx + (size_t)(16 * TC0 + li) * ld + col);
+    const Row8 b1 = load_row8(Lx + (size_t)(16 * (TC0 + 1) + li) * ld + col);
+    c00 = update_mfma(c00, a0, b0);
+    c10 = update_mfma(c10, a1, b0);
+    c11 = update_mfma(c11, a1, b1);
+    if (!dg) c01 = update_mfma(c01, a0, b1);
+  }
+  store_c_tile(Lw, ld, TR0, TC0, li, lk, c00);
+  store_c_tile(Lw, ld, TR0 + 1, TC0, li, lk, c10);
+  store_c_tile(Lw, ld, TR0 + 1, TC0 + 1, li, lk, c11);
+  if (!dg) store_c_tile(Lw, ld, TR0, TC0 + 1, li, lk, c01);
+}
+
 // panel (fused chain): trsm + update of the panel at column j in ONE kernel.  Every wave
 // computes the two 16-row pieces of X = C L_dd^-T its tile needs itself (32 MFMAs instead of
 // reading them: the panel is small and there are more idle SIMDs than tiles), turns them into
@@ -483,7 +598,30 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 640;
   if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
-  for (int j = 0; j < n32; j += GB) {
+  int NB = 256;  // super-panel width of the two-level chain: 64 / 128 / 256 / 512 -> 32.0 / 28.0 / 26.0 / 25.6 ms at n = 12000 (PSBA_CHOL_NB: development knob, multiple of 32)
+  if (const char *e = getenv("PSBA_CHOL_NB")) NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : NB;
+  const bool blocked = !fused && (n32 >= 4096 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
+  for (int J = 0; blocked && J < n32; J += NB) {
+    const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
+    for (int j = J; j < JE; j += GB) {
+      const int T0 = (j + GB) / 16, TE = JE / 16;
+      hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
+      if (j + GB < JE) {  // tiles of the super-panel's remaining columns, all rows below
+        long long tiles = 0;
+        for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
+        hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
+                           nT, TE, linv, h->status);
+      }
+    }
+    if (JE < n32) {
+      const int Tw = JE / 16;
+      const long long MR = (nT - 1 - Tw) / 2;
+      const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
+      hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
+                         JE - J, nT, Tw, linv, h->status);
+    }
+  }
+  for (int j = 0; !blocked && j < n32; j += GB) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;
     const long long M = (nT - 1) - T0;

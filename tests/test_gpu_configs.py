@@ -281,3 +281,33 @@ def test_panelwise_backward_solve(monkeypatch):
     close(dpa, dp[: o.nA], 1e-9, "dpa")
     close(h.compute_dpb(), dp, 1e-8, "dp")
     h.close()
+
+
+@pytest.mark.parametrize("n_cams", [130, 203])
+def test_two_level_blocked_panel_chain(monkeypatch, n_cams):
+    """PSBA_CHOL_BLOCKED=1 forces the chain large matrices take (super-panels of 128 columns:
+    32-column steps that update the super-panel's own columns, one K = 128 update of the rest) at
+    sizes the oracle solves quickly; 203 cameras end in a partial super-panel."""
+    import psba_amd
+    import psba_amd.synth as synth
+    monkeypatch.setenv("PSBA_CHOL_BLOCKED", "1")
+    prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=300 + n_cams)
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    h.compute_S()
+    rc, dpa = h.SPDinv_matVec()
+    assert rc == 0
+    ref = np.linalg.solve(sch["S"], sch["eab"][: o.nA])
+    close(dpa, ref, 1e-9, "dpa")
+    # a negative damping makes S indefinite: the failure must still be flagged on this chain
+    h.restore_UVdiag()
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(-1e30); h.schur_reduce(); h.schur_solve()
+    assert h.backsub(-1e30).status & 1
+    h.close()
