@@ -115,6 +115,9 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->ga);
   dev_free(h->campart);
   dev_free(h->camacc);
+  dev_free(h->cam_obs);
+  dev_free(h->cam_units);
+  h->nCamUnits = 0;
   dev_free(h->red);
   dev_free(h->items);
   dev_free(h->wg);
@@ -294,7 +297,27 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->ga_alt, (size_t)d.nA));
   h->ahead = h->lin_is_ahead = false;
   TRY(dev_alloc(h, &h->campart, h->cam_global ? 1 : (size_t)h->nPart * d.nC * CAM_ACC));
-  if (h->cam_global) TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * CAM_ACC));
+  if (h->cam_global) {
+    TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * CAM_ACC));
+    // camera-major index of the observations, cut into segments of at most 256
+    std::vector<int> cptr((size_t)nCams + 1, 0), cobs((size_t)n2Dprojs);
+    for (int a = 0; a < n2Dprojs; a++) cptr[(size_t)jidx[a] + 1]++;
+    for (int j = 0; j < nCams; j++) cptr[(size_t)j + 1] += cptr[j];
+    {
+      std::vector<int> at(cptr.begin(), cptr.end() - 1);
+      for (int a = 0; a < n2Dprojs; a++) cobs[(size_t)at[jidx[a]]++] = a;
+    }
+    std::vector<int4> units;
+    const int LSEG = 256;
+    for (int j = 0; j < nCams; j++)
+      for (int f = cptr[j]; f < cptr[(size_t)j + 1]; f += LSEG)
+        units.push_back(make_int4(j, f, std::min(f + LSEG, cptr[(size_t)j + 1]), 0));
+    h->nCamUnits = (int)units.size();
+    TRY(dev_alloc(h, &h->cam_obs, cobs.size()));
+    TRY(dev_alloc(h, &h->cam_units, units.size()));
+    PSBA_HIP(h, hipMemcpy(h->cam_obs, cobs.data(), sizeof(int) * cobs.size(), hipMemcpyHostToDevice));
+    PSBA_HIP(h, hipMemcpy(h->cam_units, units.data(), sizeof(int4) * units.size(), hipMemcpyHostToDevice));
+  }
   h->n32 = (d.nA + 31) / 32 * 32;
   // rows [0, n32 + 16) are the reduce buffer proper; n32 more rows below it are the working
   // space of the identity rows the panel chain carries along (kernels_chol_graph.hip)

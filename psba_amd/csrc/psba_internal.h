@@ -119,6 +119,11 @@ struct psba_ctx {
   // camera sums with global fp64 atomics into camacc [nC][27] (zeroed per launch) instead
   bool cam_global = false;
   double *camacc = nullptr;
+  // ... and those sums are formed by a camera-major pass: thread = (camera, segment of its
+  // observations), 27 sums in registers, one set of atomic adds per segment
+  int *cam_obs = nullptr;       // [nO] observation indices sorted by camera (stable: points ascending)
+  int4 *cam_units = nullptr;    // [nCamUnits] (camera, first, end in cam_obs, 0)
+  int nCamUnits = 0;
   // padded reduce buffer Lw[(n32+16)][n32], n32 = nA rounded up to 32: rows < nA = S (row stride
   // n32), rows nA..n32-1 identity padding, row n32 = ea, rows above zero (S_buffer, eab_buffer)
   double *red = nullptr;
