@@ -660,6 +660,15 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
 int launch_chol_graph(psba_ctx *h) {
   const int v = h->diag_done ? 1 : 0;
   h->diag_done = false;
+  // large matrices: hundreds of kernels of tens of microseconds each -- a captured graph buys
+  // nothing there (and rocprofv3's kernel tracing has been seen to crash inside the launch of a
+  // graph with ~1200 kernel nodes), so the chain is enqueued directly
+  if (h->n32 > 2048 || getenv("PSBA_CHOL_NO_GRAPH")) {
+    ProfScope ps(h, PSBA_K_CHOLESKY);
+    enqueue_chain(h, h->stream, v == 1);
+    PSBA_HIP(h, hipGetLastError());
+    return PSBA_OK;
+  }
   if (!h->chol_graph[v] || h->chol_graph_n32[v] != h->n32 || h->chol_graph_red[v] != h->red) {
     if (h->chol_graph[v]) {
       (void)hipGraphExecDestroy(h->chol_graph[v]);

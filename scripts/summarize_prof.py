@@ -10,14 +10,14 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
+stats = list(csv.DictReader(open(max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime))))
 pmc = {}
 for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(src, which, "*", "*_counter_collection.csv"))
     if not files:
         continue
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         pmc.setdefault(k, {})[counter] = sum(v) / len(v)
