@@ -163,7 +163,9 @@ __device__ __forceinline__ int tri(int j) { return j * (j + 1) / 2; }
 
 // MODE is development instrumentation (ablation timing, PSBA_SCHUR_MODE): 0 = full kernel;
 // 1 = products without the LDS atomics; 2 = no product loop; 3 = no W_b loads (wrong
-// results); 4 = zero + flush only.
+// results); 4 = zero + flush only; 5 = every row of 16 lanes on 16 distinct bank pairs by
+// construction (wrong results: what the bank conflicts of the real schedule cost); 6 = the 36
+// atomics without the 108 fp64 operations that form the values.
 template <bool DUMP, int MODE>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   extern __shared__ double sPart[];  // [nblk][37]
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
     const int a = wg.obs0 + (int)(item & 0x3FFFFu);
     const int i = wg.pt0 + (int)((item >> 18) & 0xFFFFu);
     const int boff = (int)((item >> 34) & 0x7FFu);
-    const int pos = (int)((item >> 45) & 0x3FFu);
+    int pos = (int)((item >> 45) & 0x3FFu);
+    if (MODE == 5) pos = (tid & 15) + 16 * ((pos >> 4) % (wg.nblk >> 4));
     // every address is known now: issue all loads of the product together
     const double *pv = p.PV + 9 * (size_t)i;
     const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
@@ -237,6 +240,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       continue;
     }
     double *blk = sPart + BLK_STRIDE * pos;
+    if (MODE == 6) {
+#pragma unroll
+      for (int rc = 0; rc < 36; rc++) atomicAdd(&blk[rc], wb[rc % 18]);
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
@@ -727,6 +735,10 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
         hipLaunchKernelGGL((k_schur_lds<false, 3>), G, B, lds, h->stream, a);
       else if (mode == 4)
         hipLaunchKernelGGL((k_schur_lds<false, 4>), G, B, lds, h->stream, a);
+      else if (mode == 5)
+        hipLaunchKernelGGL((k_schur_lds<false, 5>), G, B, lds, h->stream, a);
+      else if (mode == 6)
+        hipLaunchKernelGGL((k_schur_lds<false, 6>), G, B, lds, h->stream, a);
       else
         hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
     }
@@ -755,6 +767,8 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 2>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 3>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 4>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 5>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 6>, attr, dyn));
       h->lds_attr_set = true;
     }
     return launch_schur_lds(h, mu, dump);

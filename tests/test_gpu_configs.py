@@ -311,3 +311,24 @@ def test_two_level_blocked_panel_chain(monkeypatch, n_cams):
     h.schur_assemble(-1e30); h.schur_reduce(); h.schur_solve()
     assert h.backsub(-1e30).status & 1
     h.close()
+
+
+def test_single_rank_communicator_with_many_cameras(problems):
+    """The RCCL path on the many-camera routes (K1's camera-major pass, K2's owner route, the
+    all-reduce of the whole padded [S | ea] square instead of the packed triangle): results must
+    not change against a handle without a communicator."""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=460, n_pts=3000, mean_track=5.0, seed=991)
+    ref = psba_amd.Psba(0)
+    ref.upload_problem(prob)
+    want, _ = ref.levmar(max_iter=4, tr_handoff=False)
+    ref.close()
+    h = psba_amd.Psba(0)
+    h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
+    h.upload_problem(prob)
+    assert h.schur_path() == 1
+    res, _ = h.levmar(max_iter=4, tr_handoff=False)
+    assert res.iters == want.iters
+    assert abs(res.final_err - want.final_err) <= 1e-10 * want.final_err
+    h.close()
