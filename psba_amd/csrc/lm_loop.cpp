@@ -63,6 +63,11 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
       // :151-157,185-193 -- and, while the host looks at the scalars, the next iteration's
       // linearization at the proposed parameters (dropped if the step is rejected)
       LM_TRY(psba_backsub_async(h, mu));
+      // (queued before the try's status is known: after a failed factorization K3 has written
+      // non-finite proposed parameters and this linearization of them is ~35 us of wasted GPU time
+      // per failed try -- its results are dropped with the rejected step, nothing else depends on
+      // them, and skipping the launch would need the status on the host first, i.e. the very
+      // round trip the look-ahead exists to hide)
       if (itno + 1 < opts->max_iter) LM_TRY(psba_linearize_ahead(h));  // no iteration left to use it otherwise
       LM_TRY(psba_backsub_wait(h, &sc));
       if (!(sc.status & PSBA_NOT_SPD)) {
