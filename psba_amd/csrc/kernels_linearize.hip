@@ -35,7 +35,7 @@ struct LinArgs {
 template <bool DUMP, bool GACC>
 __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   __shared__ double sBE[TILE_OBS][8];  // B(6) | e(2) per observation of the tile
-  __shared__ double sW[TILE_OBS * 19];  // W blocks of the tile
+  __shared__ double sW[(TILE_OBS / 2) * 19];  // W blocks of half a tile (staged in two halves: LDS for three workgroups per CU)
   extern __shared__ double sAcc[];     // [nC][27]
   const int tid = threadIdx.x;
   const int nAcc = GACC ? 0 : p.nC * CAM_ACC;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
       pb[u][0] = ip < p1 - p0 ? p.ptr[p0 + ip] - o0 : 0;
       pb[u][1] = ip < p1 - p0 ? p.ptr[p0 + ip + 1] - o0 : 0;
     }
+    double Wv[18];
     if (a < o1) {
       double cc[9], cam[6], M[3], e[2], A[12], B[6];
 #pragma unroll
@@ -84,13 +85,18 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
         for (int k = 0; k < 6; k++) p.dbg_JB[6 * (size_t)a + k] = B[k];
       }
       // W_ij = coeff * A^T B, 6x3 row-major: staged in LDS (row stride 19 doubles: odd, so the
-      // 64 lanes of a store hit distinct banks) and written to HBM as one contiguous run per
-      // tile after the barrier, instead of 144-byte pieces at a 144-byte stride per lane
-      double *w = sW + 19 * tid;
+      // 64 lanes of a store hit distinct banks) and written to HBM as contiguous runs after the
+      // barrier, instead of 144-byte pieces at a 144-byte stride per lane -- the first half of
+      // the tile's observations now, the second half after the first is flushed
 #pragma unroll
       for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) w[3 * r + c] = p.coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+        for (int c = 0; c < 3; c++) Wv[3 * r + c] = p.coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+      if (tid < TILE_OBS / 2) {
+        double *w = sW + 19 * tid;
+#pragma unroll
+        for (int k = 0; k < 18; k++) w[k] = Wv[k];
+      }
 #pragma unroll
       for (int k = 0; k < 6; k++) sBE[tid][k] = B[k];
       sBE[tid][6] = e[0];
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
     __syncthreads();
     if (p.mode != 2) {
       double *dst = p.W + 18 * (size_t)o0;
-      const int n = 18 * (o1 - o0);
+      const int n = 18 * (o1 - o0 < TILE_OBS / 2 ? o1 - o0 : TILE_OBS / 2);
       for (int t = tid; t < n; t += TILE_OBS) dst[t] = sW[19 * (t / 18) + t % 18];
     }
     // V_i (sym6) and g_b,i: one thread per (point, component), each summing over the point's
@@ -141,6 +147,20 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
         acc += B[r] * B[c1] + B[3 + r] * B[c2];
       }
       p.PV[9 * (size_t)p0 + t] = (comp < 6 ? p.coeff : p.coeff_g) * acc;
+    }
+    if (o1 - o0 > TILE_OBS / 2) {  // (tile-uniform) second half of the W blocks through the same buffer
+      __syncthreads();
+      if (tid >= TILE_OBS / 2 && a < o1) {
+        double *w = sW + 19 * (tid - TILE_OBS / 2);
+#pragma unroll
+        for (int k = 0; k < 18; k++) w[k] = Wv[k];
+      }
+      __syncthreads();
+      if (p.mode != 2) {
+        double *dst = p.W + 18 * (size_t)(o0 + TILE_OBS / 2);
+        const int n = 18 * (o1 - o0 - TILE_OBS / 2);
+        for (int t = tid; t < n; t += TILE_OBS) dst[t] = sW[19 * (t / 18) + t % 18];
+      }
     }
     dsc = dn;
     i = j = 0;

@@ -266,7 +266,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   // beyond that its camera sums go to global memory with fp64 atomics
   h->cam_global = (size_t)CAM_ACC * nCams * sizeof(double) > 96 * 1024 || getenv("PSBA_LIN_GLOBAL_ACC");
   h->d = d;
-  h->nPart = d.nTiles < 512 ? d.nTiles : 512;
+  h->nPart = d.nTiles < 768 ? d.nTiles : 768;  // persistent workgroups: three per CU fit since W is staged in halves
   if (const char *e = getenv("PSBA_LIN_GRID")) h->nPart = atoi(e) > 0 && atoi(e) < d.nTiles ? atoi(e) : d.nTiles;
   h->cur = 0;
 

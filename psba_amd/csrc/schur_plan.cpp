@@ -46,7 +46,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   if (const char *e = getenv("PSBA_SCHUR_DUPS")) DUPS = atoi(e);
   h->packedN = 36 * (size_t)total_blocks;
   h->nGroups = 0;
-  if (nCams >= 2048) return PSBA_OK;  // boff field: track length < 2048; fall back to the atomic kernel
+  if (nCams >= 2048 || getenv("PSBA_SCHUR_OWNER")) return PSBA_OK;  // item fields; PSBA_SCHUR_OWNER forces the owner route
   // ---- camera-row groups by LDS budget: 37 doubles per block, block count padded to 16 ----
   // 100 KiB rather than all 160: smaller partitions mean less slab traffic (flush + reduce),
   // which on venice-shaped outweighs the loss of locality from more groups (scripts/k2_lds_sweep.sh)
