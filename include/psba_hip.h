@@ -86,8 +86,8 @@ int psba_reset_params(psba_handle h);
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
 /* which S-assembly route the uploaded problem takes: 0 = LDS-resident partitions of the block
- * triangle with the static schedule (camera counts up to ~220), 1 = the owner route for more
- * cameras than 64 LDS-sized camera-row groups can hold (one thread per block segment, products
+ * triangle with the static schedule (camera counts up to ~300), 1 = the owner route for more
+ * cameras than 128 LDS-sized camera-row groups can hold (one thread per block segment, products
  * sorted by camera pair, sums in registers), 2 = global fp64 atomics straight into S (the
  * first-generation kernel, kept for cross-checks: PSBA_SCHUR_ATOMIC=1).  The reference has one
  * route for every size (CL_files/compute_S.cl:6-78). */

@@ -14,7 +14,7 @@ namespace psba {
 
 constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= threads per workgroup)
 constexpr int TILE_PTS = 128;   // points per tile (bounds the per-point LDS rows)
-constexpr int MAX_GROUPS = 64;  // camera-row groups of the LDS-resident S partition (K2)
+constexpr int MAX_GROUPS = 128; // camera-row groups of the LDS-resident S partition (K2); the group tables travel as kernel arguments (< 4 KB)
 constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
 constexpr int NSCAL = 96;       // device scalar block (doubles)
 constexpr int SC_NPART = 16;    // K3's four sums arrive in 16 partial sets (same-address atomics serialise)

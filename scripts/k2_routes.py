@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import psba_amd
 from psba_amd import capi, synth
 
-for n_cams, n_pts in [(52, 64053), (96, 40000), (130, 40000), (160, 40000), (200, 40000)]:
+import sys as _s
+for n_cams, n_pts in ([(int(c), 40000) for c in _s.argv[1:]] or [(52, 64053), (96, 40000), (130, 40000), (160, 40000), (200, 40000)]):
     prob = synth.make_problem(n_cams=n_cams, n_pts=n_pts, mean_track=5.42, seed=5)
     for owner in (0, 1):
         if owner:

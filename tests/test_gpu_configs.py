@@ -174,17 +174,18 @@ def test_levmar_on_the_other_bundled_sets(cams, pts, gpu):
     assert abs(ex @ ex - res.final_err) <= 1e-9 * res.final_err + 1e-14 * ores.init_err
 
 
-@pytest.mark.parametrize("n_cams,k1_global", [(300, False), (455, False), (460, True)])
-def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global):
+@pytest.mark.parametrize("n_cams,k1_global,k2_path", [(250, False, 0), (340, False, 1), (455, False, 1), (460, True, 1)])
+def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global, k2_path):
     """Up to 455 cameras K1 keeps its 27 per-camera sums in LDS (more than 64 KiB of dynamic LDS
-    from ~270 cameras on), beyond that it adds them to global memory with fp64 atomics; K2 is on its
-    global-atomic route at all three sizes (psba_schur_path says so).  S / ea / U / g against the
-    oracle, the solve against LAPACK on the oracle's S."""
+    from ~270 cameras on), beyond that a camera-major pass forms them; K2 splits S into up to 128
+    LDS-sized camera-row groups (250 cameras: 56 groups) and takes the owner route beyond
+    (psba_schur_path says which).  S / ea / U / g against the oracle, the solve against LAPACK on
+    the oracle's S."""
     import psba_amd.synth as synth
     prob = synth.make_problem(n_cams=n_cams, n_pts=4000, mean_track=6.0, seed=7 + n_cams)
     o = Oracle(prob)
     gpu.upload_problem(prob)
-    assert gpu.schur_path() == 1
+    assert gpu.schur_path() == k2_path
     lin = o.linearize()
     close(gpu.compute_U(1.0), lin["U"], 1e-11, "U")
     close(gpu.compute_V(1.0), lin["V"], 1e-11, "V")
@@ -206,8 +207,8 @@ def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global):
     gpu.schur_assemble(mu)
     n32 = (o.nA + 31) // 32 * 32
     M = gpu.get_reduce_buffer().reshape(n32 + 1, n32)
-    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S (owner route)")
-    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea (owner route)")
+    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S (fused verb)")
+    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea (fused verb)")
     assert np.array_equal(M[o.nA: n32, o.nA:], np.eye(n32 - o.nA))
     gpu.upload_problem(prob)
     res, log = gpu.levmar(max_iter=3, tr_handoff=False)
