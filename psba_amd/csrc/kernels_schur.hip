@@ -317,9 +317,9 @@ struct SchurReduceArgs {
   // clears diag0 for the next try
   int diag_wg;
   double *diag0, *Lx, *linv;
-  // with a communicator: the sums (U, mu on rank 0 and g_a folded in) go to `packed` in slab
-  // order instead of into S -- the lower block triangle and e_a only, half the bytes of the square
-  // -- and k_schur_expand scatters them after the all-reduce
+  // with a communicator: the sums (U, mu on rank 0 and g_a folded in) go to `packed` (canonical
+  // block order) instead of into S -- the lower block triangle and e_a only, half the bytes of the
+  // square -- and k_schur_expand scatters them after the all-reduce
   double *packed;
 };
 
@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
     }
   }
   if (p.packed) {
-    p.packed[e] = unused ? 0.0 : sum;
+    // canonical order (block tri(j) + k of the lower block triangle), NOT slab order: where a
+    // block sits inside its partition is chosen per rank from that rank's own traffic counts, so
+    // slab positions do not line up between ranks
+    if (jk >= 0) p.packed[(size_t)36 * (tri(j) + jb) + rc] = unused ? 0.0 : sum;
     return;
   }
   if (unused) return;
@@ -444,11 +447,10 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
 // rank, the first step of the Cholesky chain runs beside a kernel that is needed anyway.
 struct SchurExpandArgs {
   const double *packed;
-  const int *posblock;
   double *S, *ea, *Lx, *linv;
   int *status;
   int total, nA, n32, try_id, diag_wg;
-  int diag_slot[21];  // 36 * (global position) of block (j, k), j <= 5
+  int diag_slot[21];  // 36 * (tri(j) + k): first double of block (j, k), j <= 5, in the packed sums
 };
 
 __global__ __launch_bounds__(256) void k_schur_expand(SchurExpandArgs p) {
@@ -480,9 +482,11 @@ __global__ __launch_bounds__(256) void k_schur_expand(SchurExpandArgs p) {
   write_padding(p.S, p.nA, p.n32, 1.0, gtid, (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
   const int e = (int)gtid;
   if (e >= p.total) return;
-  const int jk = p.posblock[e / 36];
-  if (jk < 0) return;
-  const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
+  const int blk = e / 36;
+  int j = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+  while ((j + 1) * (j + 2) / 2 <= blk) j++;
+  while (j * (j + 1) / 2 > blk) j--;
+  const int jb = blk - j * (j + 1) / 2, rc = e % 36, r = rc / 6, c = rc % 6;
   const double v = p.packed[e];
   if (j == jb && c > r) {
 #pragma unroll
@@ -497,7 +501,6 @@ __global__ __launch_bounds__(256) void k_schur_expand(SchurExpandArgs p) {
 int launch_schur_expand(psba_ctx *h) {
   SchurExpandArgs a;
   a.packed = h->redp;
-  a.posblock = h->posblock;
   a.S = h->red;
   a.ea = h->red + (size_t)h->n32 * h->n32;
   a.Lx = h->chol_L;
@@ -510,20 +513,8 @@ int launch_schur_expand(psba_ctx *h) {
   const int grid = (a.total + 255) / 256;
   const bool fuse = !h->diag_done && !getenv("PSBA_CHOL_SEPARATE_DIAG");
   a.diag_wg = fuse ? grid : -1;
-  int gpos0 = 0, gp[MAX_GROUPS + 1];
-  for (int g = 0; g < h->nGroups; g++) {
-    gp[g] = gpos0;
-    gpos0 += h->gnblk[g];
-  }
   for (int j = 0, b = 0; j < 6; j++)
-    for (int k = 0; k <= j; k++, b++) {
-      a.diag_slot[b] = 0;
-      if (j < h->d.nC) {
-        int g = 0;
-        while (j >= h->glo[g + 1]) g++;
-        a.diag_slot[b] = 36 * (gp[g] + h->h_diagpos[b]);
-      }
-    }
+    for (int k = 0; k <= j; k++, b++) a.diag_slot[b] = j < h->d.nC ? 36 * (j * (j + 1) / 2 + k) : 0;
   hipLaunchKernelGGL(k_schur_expand, dim3(grid + (fuse ? 1 : 0)), dim3(256), 0, h->stream, a);
   PSBA_HIP(h, hipGetLastError());
   if (fuse) h->diag_done = true;
@@ -699,7 +690,9 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   r.nGroups = h->nGroups;
   r.try_id = h->try_id;
   r.diag0 = h->diag0;
-  r.packed = h->comm ? h->redp : nullptr;
+  // (PSBA_SCHUR_PACKED: test hook -- a handle with a rank layout but no communicator takes the
+  // packed route too, and psba_get/set_reduce_buffer then move the packed sums)
+  r.packed = (h->comm || (h->nranks > 1 && getenv("PSBA_SCHUR_PACKED"))) ? h->redp : nullptr;
   h->packed_pending = r.packed != nullptr;
   r.Lx = h->chol_L;
   r.linv = h->chol_ws;

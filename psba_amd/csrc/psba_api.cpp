@@ -342,7 +342,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       PSBA_HIP(h, hipMemcpy(h->posblock, plan.posblock.data(), sizeof(int) * plan.posblock.size(), hipMemcpyHostToDevice));
       for (int j = 0, b = 0; j < 6; j++)
         for (int k = 0; k <= j; k++, b++) h->h_diagpos[b] = j < nCams ? plan.blockpos[(size_t)j * (j + 1) / 2 + k] : 0;
-      h->packed_doubles = plan.posblock.size() * 36;
+      h->packed_doubles = h->packedN;  // 36 doubles per block of the lower block triangle, canonical order
       TRY(dev_alloc(h, &h->redp, h->packed_doubles));
       TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
       PSBA_HIP(h, hipMemset(h->diag0, 0, sizeof(double) * 21 * 36));
@@ -535,10 +535,11 @@ int psba_schur_assemble(psba_handle h, double mu) {
 // padded square for the global-atomic fallback kernel
 static int allreduce_schur(psba_ctx *h) {
   if (h->packed_pending) {
-    RCCL(h, ncclAllReduce(h->redp, h->redp, h->packed_doubles, ncclDouble, ncclSum, h->comm, h->stream));
+    if (h->comm)
+      RCCL(h, ncclAllReduce(h->redp, h->redp, h->packed_doubles, ncclDouble, ncclSum, h->comm, h->stream));
     TRY(launch_schur_expand(h));
     h->packed_pending = false;
-  } else {
+  } else if (h->comm) {
     const size_t n = (size_t)(h->n32 + 1) * h->n32;  // S rows, padding rows and the ea row
     RCCL(h, ncclAllReduce(h->red, h->red, n, ncclDouble, ncclSum, h->comm, h->stream));
   }
@@ -987,10 +988,14 @@ int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
   return PSBA_OK;
 }
 
+// (with the PSBA_SCHUR_PACKED test hook the buffer is the packed [tril(S) | e_a] sums a
+// communicator would all-reduce: 36 doubles per block of the lower block triangle)
+static bool packed_hook(psba_ctx *h) { return !h->comm && h->nranks > 1 && h->nGroups > 0 && getenv("PSBA_SCHUR_PACKED"); }
+
 int psba_reduce_buffer_size(psba_handle h, long long *n_doubles) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  if (n_doubles) *n_doubles = (long long)(h->n32 + 1) * h->n32;
+  if (n_doubles) *n_doubles = packed_hook(h) ? (long long)h->packed_doubles : (long long)(h->n32 + 1) * h->n32;
   return PSBA_OK;
 }
 
@@ -998,6 +1003,7 @@ int psba_get_reduce_buffer(psba_handle h, double *out) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
   NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
+  if (packed_hook(h)) return d2h(h, out, h->redp, sizeof(double) * h->packed_doubles);
   return d2h(h, out, h->red, sizeof(double) * (size_t)(h->n32 + 1) * h->n32);
 }
 
@@ -1006,6 +1012,13 @@ int psba_set_reduce_buffer(psba_handle h, const double *in) {
   NEED(h, h->assembled, "psba_schur_assemble first");
   NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
   if (!in) return fail(h, PSBA_E_INVALID, "null buffer");
+  if (packed_hook(h)) {  // the summed packed sums: psba_schur_solve scatters them (k_schur_expand)
+    PSBA_HIP(h, hipMemcpyAsync(h->redp, in, sizeof(double) * h->packed_doubles, hipMemcpyHostToDevice, h->stream));
+    PSBA_HIP(h, hipStreamSynchronize(h->stream));
+    h->packed_pending = true;
+    h->diag_done = false;
+    return PSBA_OK;
+  }
   PSBA_HIP(h, hipMemcpyAsync(h->red, in, sizeof(double) * (size_t)(h->n32 + 1) * h->n32,
                              hipMemcpyHostToDevice, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));

@@ -333,3 +333,55 @@ def test_single_rank_communicator_with_many_cameras(problems):
     assert res.iters == want.iters
     assert abs(res.final_err - want.final_err) <= 1e-10 * want.final_err
     h.close()
+
+
+@pytest.mark.parametrize("name,nr", [("54cams", 2), ("trafalgar21", 3)])
+def test_packed_sums_line_up_between_ranks(name, nr, problems, monkeypatch):
+    """What RCCL all-reduces with a communicator is the packed [tril(S) | e_a] buffer.  Every rank
+    lays its LDS partitions out from ITS OWN traffic counts, so the packed buffer must be in an
+    order that does not depend on the rank (round 1 packed in slab order, which only lines up for
+    a single rank).  PSBA_SCHUR_PACKED=1 makes handles with a rank layout but no communicator take
+    the packed route and psba_get/set_reduce_buffer move the packed sums: the all-reduce is then
+    done by hand over shards whose plans differ, and the result must be the single-handle try."""
+    import psba_amd
+    from psba_amd import capi
+    monkeypatch.setenv("PSBA_SCHUR_PACKED", "1")
+    prob = problems[name]
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, _ = o.solve(lin, sch)
+    hs = []
+    for r in range(nr):
+        h = psba_amd.Psba(0)
+        h.set_rank_layout(nr, r)
+        h.upload_problem(capi.shard_problem(prob, nr, r))
+        assert h.schur_path() == 0
+        h.linearize(1.0, 1.0)
+        h.schur_assemble(mu)
+        hs.append(h)
+    nblk = o.nC * (o.nC + 1) // 2
+    assert hs[0].reduce_buffer_size() == 36 * nblk
+    total = sum(h.get_reduce_buffer() for h in hs)
+    # the packed sums are the lower block triangle of S in canonical block order
+    P = total.reshape(nblk, 6, 6)
+    b = 0
+    for j in range(o.nC):
+        for k in range(j + 1):
+            want = sch["S"][6 * j: 6 * j + 6, 6 * k: 6 * k + 6]
+            got = P[b] if j != k else np.tril(P[b]) + np.tril(P[b], -1).T
+            assert np.abs(got - want).max() <= 1e-11 * np.abs(sch["S"]).max(), (j, k)
+            b += 1
+    props = []
+    for h in hs:
+        h.set_reduce_buffer(total)
+        h.schur_solve()
+        sc = h.backsub(mu)
+        assert sc.status == 0
+        props.append(h.get_params(1))
+    newp = np.r_[o.cams, o.pts] + dp
+    flat = np.r_[props[0][0].reshape(-1), np.concatenate([p.reshape(-1) for _, p in props])]
+    close(flat, newp, 1e-9, "proposal over the shards")
+    for h in hs:
+        h.close()
