@@ -343,6 +343,135 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide(double *Lw, double *L
   if (!dg) store_c_tile(Lw, ld, TR0, TC0 + 1, li, lk, c01);
 }
 
+// The same update with a 64x64 block (4x4 MFMA tiles) per wave.  With 2x2 tiles a wave fetches
+// 256 B of operands per lane for 32 MFMAs and reads its C tiles before it starts; here every
+// 64-byte operand piece feeds four MFMA chains, the next 32-column step's pieces are fetched while
+// the current 128 MFMAs run, and the accumulators start at zero so that the C tiles (the HBM
+// traffic of the update: the whole trailing triangle once per super-panel) are fetched during the
+// last step instead of in front of the first.  FULL: all sixteen tiles are inside the triangle
+// (no per-tile tests in the MFMA sequence); otherwise tiles above the diagonal, beyond the last
+// tile row (ragged edge) or owned by workgroup 0 are skipped.
+template <bool FULL>
+__device__ __forceinline__ void wide4_block(double *Lw, const double *Lx, int ld, int J, int KW, int Tw, int last,
+                                            int TR0, int TC0, int li, int lk) {
+  bool on[4][4];
+  d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int TR = TR0 + a, TC = TC0 + b;
+      on[a][b] = FULL || (TR <= last && TC <= TR && !(TR <= Tw + 1 && TC <= Tw + 1));
+      acc[a][b] = d4{0, 0, 0, 0};
+    }
+  // rows beyond the last tile row are read from row `last` instead (their products are not used)
+  const double *pa[4], *pb[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int TR = TR0 + a <= last ? TR0 + a : last, TC = TC0 + a <= last ? TC0 + a : last;
+    pa[a] = Lx + (size_t)(16 * TR + li) * ld + J + 8 * lk;
+    pb[a] = Lx + (size_t)(16 * TC + li) * ld + J + 8 * lk;
+  }
+  // two operand buffers used in turn (no register copies between steps: a copy makes the compiler
+  // wait for the fetch in the middle of the MFMA sequence it is meant to hide behind)
+  Row8 a0[4], b0[4], a1[4], b1[4];
+#define WIDE4_LOAD(A, B, off)                          \
+  _Pragma("unroll") for (int a = 0; a < 4; a++) {      \
+    A[a] = load_row8(pa[a] + (off));                   \
+    B[a] = load_row8(pb[a] + (off));                   \
+  }
+#define WIDE4_MFMAS(A, B)                                                                         \
+  _Pragma("unroll") for (int t = 0; t < 8; t++) _Pragma("unroll") for (int a = 0; a < 4; a++)     \
+      _Pragma("unroll") for (int b = 0; b < 4; b++) if (on[a][b]) acc[a][b] =                     \
+          __builtin_amdgcn_mfma_f64_16x16x4f64(A[a].v[t], B[b].v[t], acc[a][b], 0, 0, 0)
+  // KW is a multiple of 2 GB (the host takes the 2x2-tile kernel otherwise)
+  int kk = 0;
+  WIDE4_LOAD(a0, b0, 0);
+  // (the scheduling barriers keep each fetch where it is written: hoisted further up, three operand
+  // sets are live at once and the kernel spills)
+#define WIDE4_FENCE() __builtin_amdgcn_sched_barrier(0)
+  for (; kk + 2 * GB < KW; kk += 2 * GB) {
+    WIDE4_FENCE();
+    WIDE4_LOAD(a1, b1, kk + GB);
+    WIDE4_FENCE();
+    WIDE4_MFMAS(a0, b0);
+    WIDE4_FENCE();
+    WIDE4_LOAD(a0, b0, kk + 2 * GB);
+    WIDE4_FENCE();
+    WIDE4_MFMAS(a1, b1);
+  }
+  WIDE4_FENCE();
+  WIDE4_LOAD(a1, b1, kk + GB);
+  WIDE4_FENCE();
+  WIDE4_MFMAS(a0, b0);
+  WIDE4_FENCE();
+  d4 c[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (on[a][b]) c[a][b] = load_c_tile(Lw, ld, TR0 + a, TC0 + b, li, lk);
+  WIDE4_FENCE();
+  WIDE4_MFMAS(a1, b1);
+#undef WIDE4_FENCE
+#undef WIDE4_MFMAS
+#undef WIDE4_LOAD
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (on[a][b]) store_c_tile(Lw, ld, TR0 + a, TC0 + b, li, lk, c[a][b] - acc[a][b]);
+}
+
+// Workgroup 0: the next diagonal block + its factorization and the e_a tile row's first tiles are as
+// in k_cholg_update_wide; every other wave owns one 64x64 block of the lower triangle of the
+// trailing square, or one tile of the e_a tile row.
+__global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *Lx, int ld, int J, int KW, int nT,
+                                                            int Tw, double *linv, int *status) {
+  __shared__ Factor32Lds s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  if (blockIdx.x == 0) {
+    if (tid < 4) s.flag[tid] = 0;
+    if (tid == 4) s.fail = 0;
+    if (wave < 3) {
+      const int TR = Tw + (wave > 0), TC = Tw + (wave > 1);
+      const d4 c = update_tile_k(Lw, Lx, ld, J, KW, TR, TC, li, lk);
+#pragma unroll
+      for (int r = 0; r < 4; r++) s.D[16 * (TR - Tw) + lk + 4 * r][16 * (TC - Tw) + li] = c[r];
+    }
+    __syncthreads();
+    factor_next(s, Lx, ld, 16 * Tw, linv, status, tid);
+    return;
+  }
+  // (grouping the blocks in 8x8 patches per XCD took the L2 misses from 41 % to 23 % of the requests
+  // and the kernel from 276 to 292 us: the operand re-reads are served by the Infinity Cache fast
+  // enough, the uneven patch counts per XCD cost more -- row-major block order it is)
+  const int nTl = nT - 1 - Tw;                 // tile rows of the trailing square (without the e_a row)
+  const long long MR = (nTl + 3) / 4;          // 64-row block rows
+  const long long ntri = MR * (MR + 1) / 2;
+  const long long idx = (long long)(blockIdx.x - 1) * 4 + wave;
+  if (idx >= ntri) {
+    const long long e = idx - ntri;  // e_a tile row
+    if (e >= nTl) return;
+    const int TC = Tw + (int)e;
+    store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
+    return;
+  }
+  int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+  while ((long long)m * (m + 1) / 2 > idx) m--;
+  m = __builtin_amdgcn_readfirstlane(m);
+  const int mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+  const int TR0 = Tw + 4 * m, TC0 = Tw + 4 * mc;
+  const int last = nT - 2;  // last tile row / column of the square
+  if (mc < m && TR0 + 3 <= last && (m > 0))
+    wide4_block<true>(Lw, Lx, ld, J, KW, Tw, last, TR0, TC0, li, lk);
+  else
+    wide4_block<false>(Lw, Lx, ld, J, KW, Tw, last, TR0, TC0, li, lk);
+}
+
 // panel (fused chain): trsm + update of the panel at column j in ONE kernel.  Every wave
 // computes the two 16-row pieces of X = C L_dd^-T its tile needs itself (32 MFMAs instead of
 // reading them: the panel is small and there are more idle SIMDs than tiles), turns them into
@@ -615,10 +744,17 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     }
     if (JE < n32) {
       const int Tw = JE / 16;
-      const long long MR = (nT - 1 - Tw) / 2;
-      const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
-      hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
-                         JE - J, nT, Tw, linv, h->status);
+      if (getenv("PSBA_CHOL_WIDE2") || (JE - J) % (2 * GB)) {  // the 2x2-tile kernel (any width; for comparison)
+        const long long MR = (nT - 1 - Tw) / 2;
+        const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
+        hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
+                           JE - J, nT, Tw, linv, h->status);
+      } else {
+        const long long MR = (nT - 1 - Tw + 3) / 4;
+        const unsigned grid = 1 + (unsigned)((MR * (MR + 1) / 2 + (nT - 1 - Tw) + 3) / 4);  // diag; 64x64 blocks, e_a tiles
+        hipLaunchKernelGGL(k_cholg_update_wide4, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, J,
+                           JE - J, nT, Tw, linv, h->status);
+      }
     }
   }
   for (int j = 0; !blocked && j < n32; j += GB) {

@@ -12,4 +12,5 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="$REPO/bench.py --workload cfg5 --cfg5-points $PTS --steps 4 --warmup 1 --segment 2 --spread-segments 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -f csv -d $OUT/pmc_mfma -- python3 $ARGS > $OUT/bench_mfma.json 2> $OUT/mfma.log
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/pmc_l2 -- python3 $ARGS > $OUT/bench_l2.json 2> $OUT/l2.log
 find $OUT -name "*.csv" | head -20
