@@ -86,9 +86,10 @@ int psba_reset_params(psba_handle h);
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
 /* which S-assembly route the uploaded problem takes: 0 = LDS-resident partitions of the block
- * triangle with the static schedule (camera counts up to ~300), 1 = the owner route for more
- * cameras than 128 LDS-sized camera-row groups can hold (one thread per block segment, products
- * sorted by camera pair, sums in registers), 2 = global fp64 atomics straight into S (the
+ * triangle with the static schedule (fewer than 2048 cameras, up to 4.19 M observations and 2.1 M
+ * points on this rank), 1 = the owner route for larger problems (one thread per block segment,
+ * products sorted by camera pair, sums in registers; PSBA_SCHUR_OWNER=1 forces it), 2 = global
+ * fp64 atomics straight into S (the
  * first-generation kernel, kept for cross-checks: PSBA_SCHUR_ATOMIC=1).  The reference has one
  * route for every size (CL_files/compute_S.cl:6-78). */
 int psba_schur_path(psba_handle h, int *path);
@@ -321,7 +322,8 @@ int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
  * blkIdx_buffer look-ups (CL_files/compute_S.cl:13-22); here it is data that can be checked.
  * info[0..5] = groups, workgroups, item slots, products, slab doubles, blocks nC(nC+1)/2.
  * psba_schur_plan_copy: items[info[2]]; wg[info[1]][7] = group, blocks in partition, obs0, pt0,
- * first item, end item, slab offset; blockpos[info[5]]; glo[groups+1].  Any pointer may be NULL. */
+ * first item, end item, slab offset; blockpos[info[5]]; glo[groups+1]: group g owns the blocks
+ * [glo[g], glo[g+1]) of the canonical order j (j + 1) / 2 + k.  Any pointer may be NULL. */
 typedef struct psba_schur_plan *psba_schur_plan_t;
 psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
                                          const int *jidx);

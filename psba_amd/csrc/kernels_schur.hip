@@ -181,10 +181,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
     const unsigned long long item = p.items[t];
     if (item == SCHUR_NULL_ITEM) continue;
-    const int a = wg.obs0 + (int)(item & 0x3FFFFu);
-    const int i = wg.pt0 + (int)((item >> 18) & 0xFFFFu);
-    const int boff = (int)((item >> 34) & 0x7FFu);
-    int pos = (int)((item >> 45) & 0x3FFu);
+    const int a = wg.obs0 + (int)(item & ((1u << ITEM_OBS_BITS) - 1));
+    const int i = wg.pt0 + (int)((item >> ITEM_OBS_BITS) & ((1u << ITEM_PT_BITS) - 1));
+    const int boff = (int)((item >> (ITEM_OBS_BITS + ITEM_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
+    int pos = (int)(item >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
     if (MODE == 5) pos = (tid & 15) + 16 * ((pos >> 4) % (wg.nblk >> 4));
     // every address is known now: issue all loads of the product together
     const double *pv = p.PV + 9 * (size_t)i;
@@ -309,8 +309,9 @@ struct SchurReduceArgs {
   int *status;
   double mu_add, pad_one;
   int nA, n32, nGroups, try_id;
-  int gnwg[MAX_GROUPS], gnblk[MAX_GROUPS], gpos0[MAX_GROUPS + 1];  // gpos0: first position of a group
-  unsigned long long gslab[MAX_GROUPS];
+  const ReduceGroup *grp16;  // per run of 16 positions (= 9 chunks): its group's slabs, partition size, first position, slab offset
+  int chunks;         // 512-byte chunks per workgroup: 1, 2, 4 or 8 (x 8 / chunks slab sequences)
+  long long nchunks;  // 18 * positions / 32
   // single rank: workgroup diag_wg (one past the regular ones, -1: off) takes the first 32x32
   // diagonal block of S as summed into diag0 by the K2 workgroups, factors it (the first step
   // of the Cholesky chain: otherwise a kernel of its own with one CU busy and 255 idle) and
@@ -358,58 +359,11 @@ __device__ __forceinline__ void reduce_first_diag_block(const SchurReduceArgs &p
   if (tid == 0 && s.fail) p.status[1] = p.try_id;
 }
 
-__global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
-  __shared__ double2 sAcc[8][32];
-  __shared__ Factor32Lds sF;
-  if ((int)blockIdx.x == p.diag_wg) {
-    reduce_first_diag_block(p, sF);
-    return;
-  }
-  // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
-  // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
-  if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) p.scal[SC_PART + threadIdx.x] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x == 64) p.status[3] = p.try_id;
-  if (!p.packed)
-    write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
-                  (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
-  // a workgroup owns 32 consecutive pairs of doubles (512 bytes of every slab of its group: 36 is
-  // even, so a pair never straddles a block, and a partition is a multiple of 16 blocks = 9 x 32
-  // pairs, so a workgroup never straddles groups); eight interleaved slab sequences, 16-byte loads,
-  // four of them in flight per thread
-  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
-  const int e2 = blockIdx.x * 32 + o;  // pair 18 * (global position) + rc / 2
-  int g = 0;
-  while (g + 1 < p.nGroups && blockIdx.x * 32 >= 18 * p.gpos0[g + 1]) g++;
-  const int n = p.gnwg[g];
-  const size_t stride = (size_t)18 * p.gnblk[g];  // in pairs
-  const double2 *s = reinterpret_cast<const double2 *>(p.slab + p.gslab[g]) + (e2 - 18 * p.gpos0[g]);
-  double2 acc = make_double2(0.0, 0.0);
-  int k = q;
-  for (; k + 24 < n; k += 32) {
-    const double2 x0 = s[(size_t)k * stride];
-    const double2 x1 = s[(size_t)(k + 8) * stride];
-    const double2 x2 = s[(size_t)(k + 16) * stride];
-    const double2 x3 = s[(size_t)(k + 24) * stride];
-    acc.x += x0.x; acc.y += x0.y;
-    acc.x += x1.x; acc.y += x1.y;
-    acc.x += x2.x; acc.y += x2.y;
-    acc.x += x3.x; acc.y += x3.y;
-  }
-  for (; k < n; k += 8) {
-    const double2 x = s[(size_t)k * stride];
-    acc.x += x.x; acc.y += x.y;
-  }
-  sAcc[q][o] = acc;
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  // one thread per double from here
-  const int po = threadIdx.x >> 1, hi = threadIdx.x & 1;
-  double sum = 0.0;
-#pragma unroll
-  for (int t = 0; t < 8; t++) sum += hi ? sAcc[t][po].y : sAcc[t][po].x;
-  const int e = 2 * (blockIdx.x * 32 + po) + hi;  // slot 36 * (global position) + rc
+// where slot e = 36 * (global position) + rc of the summed slabs goes: adds blockdiag(U) + mu_add I and
+// g_a and writes S (both block triangles) / e_a, or the packed buffer
+__device__ __forceinline__ void reduce_scatter(const SchurReduceArgs &p, long long e, double sum) {
   const int jk = p.posblock[e / 36];
-  const int j = jk >> 16, jb = jk & 0xFFFF, rc = e % 36, r = rc / 6, c = rc % 6;
+  const int j = jk >> 16, jb = jk & 0xFFFF, rc = (int)(e % 36), r = rc / 6, c = rc % 6;
   int ea_slot = -1;  // a diagonal block holds its lower triangle; six upper slots carry e_a, the rest is unused
   if (jk >= 0 && j == jb && c > r) {
 #pragma unroll
@@ -439,6 +393,71 @@ __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   }
   p.S[(size_t)(6 * jb + c) * p.n32 + 6 * j + r] = sum;
   p.S[(size_t)(6 * j + r) * p.n32 + 6 * jb + c] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
+  __shared__ double2 sAcc[8][32];
+  __shared__ Factor32Lds sF;
+  if ((int)blockIdx.x == p.diag_wg) {
+    reduce_first_diag_block(p, sF);
+    return;
+  }
+  // the accumulators of this try's K3 (||dp||^2, gain denominator, new cost, ||p+dp||^2), and
+  // the try stamp the (graph-replayed, hence argument-frozen) Cholesky kernels write on failure
+  if (blockIdx.x == 0 && threadIdx.x < 4 * SC_NPART) p.scal[SC_PART + threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 64) p.status[3] = p.try_id;
+  if (!p.packed)
+    write_padding(p.S, p.nA, p.n32, p.pad_one, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (size_t)(gridDim.x - (p.diag_wg >= 0 ? 1 : 0)) * blockDim.x);
+  // a chunk is 32 consecutive pairs of doubles (512 bytes of every slab of its group: 36 is even,
+  // so a pair never straddles a block, and a partition is a multiple of 16 blocks = 9 x 32 pairs,
+  // so a chunk never straddles groups).  A workgroup takes `chunks` (1, 2, 4 or 8) chunks with
+  // 8 / chunks interleaved slab sequences each: one chunk with eight sequences where a group has
+  // many slabs, eight chunks with one where every group has a single slab (many cameras: the kernel
+  // then is a permutation, and 512-byte workgroups were ~300 k launches of almost idle threads).
+  // 16-byte loads, four of them in flight per thread.
+  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int L = 8 / p.chunks, slot = q / L, sub = q % L;
+  const long long chunk = (long long)blockIdx.x * p.chunks + slot;
+  double2 acc = make_double2(0.0, 0.0);
+  if (chunk < p.nchunks) {
+    const ReduceGroup gr = p.grp16[chunk / 9];  // 16 positions = 9 chunks; one 32-byte load, no look-up chain
+    const int n = gr.nwg;
+    const size_t stride = (size_t)18 * gr.nblk;  // in pairs
+    const double2 *s = reinterpret_cast<const double2 *>(p.slab + gr.slab) + (chunk * 32 + o - 18LL * gr.pos0);
+    int k = sub;
+    for (; k + 3 * L < n; k += 4 * L) {
+      const double2 x0 = s[(size_t)k * stride];
+      const double2 x1 = s[(size_t)(k + L) * stride];
+      const double2 x2 = s[(size_t)(k + 2 * L) * stride];
+      const double2 x3 = s[(size_t)(k + 3 * L) * stride];
+      acc.x += x0.x; acc.y += x0.y;
+      acc.x += x1.x; acc.y += x1.y;
+      acc.x += x2.x; acc.y += x2.y;
+      acc.x += x3.x; acc.y += x3.y;
+    }
+    for (; k < n; k += L) {
+      const double2 x = s[(size_t)k * stride];
+      acc.x += x.x; acc.y += x.y;
+    }
+  }
+  if (L == 1) {  // every slot has summed its chunk alone: no exchange
+    if (chunk < p.nchunks) {
+      reduce_scatter(p, 2 * (chunk * 32 + o), acc.x);
+      reduce_scatter(p, 2 * (chunk * 32 + o) + 1, acc.y);
+    }
+    return;
+  }
+  sAcc[q][o] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x >= 64 * p.chunks) return;
+  // one thread per double from here
+  const int fslot = threadIdx.x >> 6, po = (threadIdx.x & 63) >> 1, hi = threadIdx.x & 1;
+  const long long fchunk = (long long)blockIdx.x * p.chunks + fslot;
+  if (fchunk >= p.nchunks) return;
+  double sum = 0.0;
+  for (int t = 0; t < L; t++) sum += hi ? sAcc[fslot * L + t][po].y : sAcc[fslot * L + t][po].x;
+  reduce_scatter(p, 2 * (fchunk * 32 + po) + hi, sum);
 }
 
 // after the all-reduce of the packed sums: scatter them into the padded row-major S (both block
@@ -664,16 +683,10 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   const bool fuse_diag = h->nranks == 1 && h->diag0 && !getenv("PSBA_CHOL_SEPARATE_DIAG") &&
                          !getenv("PSBA_SCHUR_NO_FLUSH_DIAG");
   a.diag0 = fuse_diag ? h->diag0 : nullptr;
-  for (int j = 0, b = 0; j < 6; j++)
-    for (int k = 0; k <= j; k++, b++) {
-      int g = -1;
-      if (j < d.nC) {
-        g = 0;
-        while (j >= h->glo[g + 1]) g++;
-      }
-      a.diag_grp[b] = g;
-      a.diag_pos[b] = h->h_diagpos[b];
-    }
+  for (int b = 0; b < 21; b++) {
+    a.diag_grp[b] = h->h_diaggrp[b];
+    a.diag_pos[b] = h->h_diagpos[b];
+  }
   SchurReduceArgs r;
   r.slab = h->slab;
   r.U = h->U;
@@ -697,16 +710,19 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   r.Lx = h->chol_L;
   r.linv = h->chol_ws;
   int worst = 0;
-  r.gpos0[0] = 0;
+  long long npos = 0;
   for (int g = 0; g < h->nGroups; g++) {
-    r.gnwg[g] = h->gnwg[g];
-    r.gnblk[g] = h->gnblk[g];
-    r.gslab[g] = h->gslab[g];
-    r.gpos0[g + 1] = r.gpos0[g] + h->gnblk[g];
+    npos += h->gnblk[g];
     if (h->gnblk[g] > worst) worst = h->gnblk[g];
   }
   const size_t lds = sizeof(double) * BLK_STRIDE * (size_t)worst;
-  const int rgrid = 36 * r.gpos0[h->nGroups] / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
+  int most = 1;
+  for (int g = 0; g < h->nGroups; g++) most = h->gnwg[g] > most ? h->gnwg[g] : most;
+  r.grp16 = h->gtab;
+  r.chunks = most > 16 ? 1 : most > 8 ? 2 : most > 4 ? 4 : 8;  // up to four slabs: a thread sums them alone
+  if (const char *e = getenv("PSBA_REDUCE_CHUNKS")) r.chunks = atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8 ? atoi(e) : 1;
+  r.nchunks = 36 * npos / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
+  const int rgrid = (int)((r.nchunks + r.chunks - 1) / r.chunks);
   r.diag_wg = fuse_diag ? rgrid : -1;
   // timing classes: PSBA_K_SCHUR alone = one span over both kernels (S exists only after the
   // reduce: that pair is the graded kernel); with PSBA_K_SCHUR_REDUCE also on, each kernel by itself

@@ -122,6 +122,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->items);
   dev_free(h->wg);
   dev_free(h->posblock);
+  dev_free(h->gtab);
   dev_free(h->diag0);
   dev_free(h->redp);
   dev_free(h->slab);
@@ -341,7 +342,23 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       PSBA_HIP(h, hipMemcpy(h->wg, plan.wgs.data(), sizeof(SchurWg) * plan.wgs.size(), hipMemcpyHostToDevice));
       PSBA_HIP(h, hipMemcpy(h->posblock, plan.posblock.data(), sizeof(int) * plan.posblock.size(), hipMemcpyHostToDevice));
       for (int j = 0, b = 0; j < 6; j++)
-        for (int k = 0; k <= j; k++, b++) h->h_diagpos[b] = j < nCams ? plan.blockpos[(size_t)j * (j + 1) / 2 + k] : 0;
+        for (int k = 0; k <= j; k++, b++) {
+          h->h_diagpos[b] = j < nCams ? plan.blockpos[(size_t)b] : 0;
+          int g = -1;
+          if (j < nCams)
+            for (g = 0; b >= h->gblk0[g + 1];) g++;
+          h->h_diaggrp[b] = g;
+        }
+      {
+        std::vector<ReduceGroup> tab;
+        long long pos0 = 0;
+        for (int g = 0; g < h->nGroups; g++) {
+          tab.insert(tab.end(), (size_t)h->gnblk[g] / 16, ReduceGroup{h->gnwg[g], h->gnblk[g], pos0, h->gslab[g], 0});
+          pos0 += h->gnblk[g];
+        }
+        TRY(dev_alloc(h, &h->gtab, tab.size()));
+        PSBA_HIP(h, hipMemcpy(h->gtab, tab.data(), sizeof(ReduceGroup) * tab.size(), hipMemcpyHostToDevice));
+      }
       h->packed_doubles = h->packedN;  // 36 doubles per block of the lower block triangle, canonical order
       TRY(dev_alloc(h, &h->redp, h->packed_doubles));
       TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
@@ -1164,8 +1181,8 @@ int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long lo
       o[4] = w.item0; o[5] = w.item1; o[6] = (long long)w.slab_off;
     }
   if (blockpos) std::copy(p->plan.blockpos.begin(), p->plan.blockpos.end(), blockpos);
-  if (glo)
-    for (int g = 0; g <= p->ctx.nGroups; g++) glo[g] = p->ctx.glo[g];
+  if (glo)  // block ranges: group g owns the blocks [glo[g], glo[g + 1]) of the canonical order tri(j) + k
+    for (int g = 0; g <= p->ctx.nGroups; g++) glo[g] = p->ctx.gblk0[g];
   return PSBA_OK;
 }
 

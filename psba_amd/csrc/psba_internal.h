@@ -14,7 +14,7 @@ namespace psba {
 
 constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= threads per workgroup)
 constexpr int TILE_PTS = 128;   // points per tile (bounds the per-point LDS rows)
-constexpr int MAX_GROUPS = 128; // camera-row groups of the LDS-resident S partition (K2); the group tables travel as kernel arguments (< 4 KB)
+constexpr int MAX_GROUPS = 128; // row-aligned groups of the LDS-resident S partition (K2) are tried up to this count, then ranges of blocks
 constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
 constexpr int NSCAL = 96;       // device scalar block (doubles)
 constexpr int SC_NPART = 16;    // K3's four sums arrive in 16 partial sets (same-address atomics serialise)
@@ -43,13 +43,24 @@ struct Dims {
 };
 
 // one workgroup of k_schur_lds: a range of work items of one camera-row group
+// item = (a - obs0) | (i - pt0) << 22 | (a - b) << 43 | position << 54: observation (22 bits), point
+// (21 bits), distance to the partner observation of the same point (11 bits), block position in the
+// partition (10 bits)
+constexpr int ITEM_OBS_BITS = 22, ITEM_PT_BITS = 21, ITEM_BOFF_BITS = 11, ITEM_POS_BITS = 10;
 struct SchurWg {
-  int group, nblk;      // camera-row group; blocks in its LDS partition
+  int group, nblk;      // group of blocks; blocks in its LDS partition
   int obs0, pt0;        // the items' observation / point numbers are relative to these
   long long item0, item1;
   unsigned long long slab_off;  // where this workgroup's partition goes in psba_ctx::slab
 };
 constexpr unsigned long long SCHUR_NULL_ITEM = ~0ull;
+// what k_schur_reduce needs to know about the group a run of 16 partition positions belongs to
+struct ReduceGroup {
+  int nwg, nblk;            // slabs of the group, blocks in its partition
+  long long pos0;           // first (global) position of the group
+  unsigned long long slab;  // first double of the group's slabs
+  unsigned long long pad;
+};
 
 // K2's route for many cameras (no LDS partition can hold a useful part of S): one thread per
 // unit = (block of the lower block triangle, a segment of that block's product list); the
@@ -129,12 +140,13 @@ struct psba_ctx {
   double *red = nullptr;
   int n32 = 0;
   // K2 (schur) static schedule, built once per problem by schur_plan.cpp
-  int nGroups = 0;              // camera-row groups; 0: fall back to global atomics
+  int nGroups = 0;              // groups of blocks (one LDS partition each); 0: the owner route
   int nWg = 0;                  // workgroups of k_schur_lds
-  int glo[psba::MAX_GROUPS + 1] = {0};   // group g owns camera rows [glo[g], glo[g+1])
-  int gnwg[psba::MAX_GROUPS] = {0};      // workgroups (= slabs) of group g
-  int gnblk[psba::MAX_GROUPS] = {0};     // blocks in group g's LDS partition (padded to 16)
-  size_t gslab[psba::MAX_GROUPS] = {0};  // first double of group g's slabs
+  std::vector<int> gblk0;       // group g owns the blocks [gblk0[g], gblk0[g+1]) of the canonical order tri(j) + k
+  std::vector<int> gnwg;        // workgroups (= slabs) of group g
+  std::vector<int> gnblk;       // blocks in group g's LDS partition (padded to 16)
+  std::vector<size_t> gslab;    // first double of group g's slabs
+  psba::ReduceGroup *gtab = nullptr;  // device, for k_schur_reduce: one entry per run of 16 partition positions
   psba::SchurWg *wg = nullptr;  // [nWg] ordered by position in the point sequence
   unsigned long long *items = nullptr;   // work items, one per product Y_a W_b^T (or null)
   // single rank: the K2 workgroups add their copies of the 21 blocks of the first 32x32 diagonal
@@ -145,6 +157,7 @@ struct psba_ctx {
   bool packed_pending = false;  // this try's sums sit in redp, not yet in red
   double *diag0 = nullptr;      // [21 * 36], zero between tries
   int h_diagpos[21] = {0};      // partition positions of the blocks (j, k), j <= 5
+  int h_diaggrp[21] = {0};      // and their groups (-1: no such camera)
   bool diag_done = false;       // this try's S-reduce kernel has factored the first diagonal block
   int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position

@@ -40,7 +40,6 @@ int WINDOW = 3;               // open rows while dealing: more rows fill better 
 
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
                      const int *ptr, SchurPlanHost &out) {
-  (void)nPts;
   const long long total_blocks = tri(nCams);
   if (const char *e = getenv("PSBA_SCHUR_WINDOW")) WINDOW = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = getenv("PSBA_SCHUR_DUPS")) DUPS = atoi(e);
@@ -75,19 +74,41 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     }
     if (h->nGroups) break;
   }
-  if (!h->nGroups) return PSBA_OK;
+  h->gblk0.clear();
+  if (h->nGroups && !getenv("PSBA_SCHUR_BLOCK_GROUPS")) {
+    for (int g = 0; g <= h->nGroups; g++) h->gblk0.push_back((int)tri(lo[g]));
+  } else {
+    // more cameras than row-aligned groups hold (a camera row alone outgrows a partition from ~550
+    // cameras on): consecutive ranges of the canonical block order, whole LDS each.  With at least
+    // one workgroup per group the slabs then are one copy of tril(S) whatever the partition size,
+    // so the largest partition it is (fewer workgroups, longer item lists each).
+    size_t budget_blocks = (size_t)159 * 1024 / sizeof(double) / 37 / ROW * ROW;
+    if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_blocks = (size_t)atoi(e) * 1024 / sizeof(double) / 37 / ROW * ROW;
+    if (budget_blocks > 1008) budget_blocks = 1008;
+    const long long G = (total_blocks + (long long)budget_blocks - 1) / (long long)budget_blocks;
+    if (36 * 8 * (double)total_blocks > 1.5e9) return PSBA_OK;  // slabs + reduce traffic beyond what the owner route costs
+    // one workgroup per group walks the whole point sequence: the item fields must hold it
+    if (nObs >= (1 << ITEM_OBS_BITS) || nPts >= (1 << ITEM_PT_BITS)) return PSBA_OK;
+    h->nGroups = (int)G;
+    for (long long g = 0; g <= G; g++) h->gblk0.push_back((int)(total_blocks * g / G));
+  }
   const int G = h->nGroups;
-  for (int g = 0; g <= G; g++) h->glo[g] = lo[g];
-  std::vector<int> grp_of_cam((size_t)nCams);
+  h->gnwg.assign((size_t)G, 1);
+  h->gnblk.assign((size_t)G, 0);
+  h->gslab.assign((size_t)G, 0);
+  std::vector<int> grp_of_blk((size_t)total_blocks);
   for (int g = 0; g < G; g++)
-    for (int j = lo[g]; j < lo[g + 1]; j++) grp_of_cam[j] = g;
+    for (int b = h->gblk0[g]; b < h->gblk0[g + 1]; b++) grp_of_blk[(size_t)b] = g;
 
   // ---- traffic per block and per group ----
   std::vector<long long> traffic((size_t)total_blocks, 0), gitems((size_t)G, 0);
   for (int a = 0; a < nObs; a++) {
-    const int ja = jidx[a];
-    for (int b = ptr[iidx[a]]; b <= a; b++) traffic[(size_t)(tri(ja) + jidx[b])]++;
-    gitems[grp_of_cam[ja]] += a - ptr[iidx[a]] + 1;
+    const long long base = tri(jidx[a]);
+    for (int b = ptr[iidx[a]]; b <= a; b++) {
+      const size_t blk = (size_t)(base + jidx[b]);
+      traffic[blk]++;
+      gitems[grp_of_blk[blk]]++;
+    }
   }
   const long long total_items = std::accumulate(gitems.begin(), gitems.end(), 0LL);
 
@@ -95,7 +116,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   // bank pair (position mod 16) with the least traffic so far that still has a free position ----
   out.blockpos.assign((size_t)total_blocks, 0);
   for (int g = 0; g < G; g++) {
-    const long long b0 = tri(lo[g]), nb = tri(lo[g + 1]) - b0;
+    const long long b0 = h->gblk0[g], nb = h->gblk0[g + 1] - b0;
     const int per = (int)((nb + ROW - 1) / ROW);
     h->gnblk[g] = per * ROW;
     std::vector<int> order((size_t)nb);
@@ -115,11 +136,15 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   }
 
   out.posblock.clear();
-  for (int g = 0; g < G; g++) {
-    const size_t base = out.posblock.size();
-    out.posblock.resize(base + (size_t)h->gnblk[g], -1);
-    for (int j = lo[g]; j < lo[g + 1]; j++)
-      for (int k = 0; k <= j; k++) out.posblock[base + (size_t)out.blockpos[(size_t)(tri(j) + k)]] = (j << 16) | k;
+  {
+    std::vector<size_t> base((size_t)G);
+    for (int g = 0; g < G; g++) {
+      base[g] = out.posblock.size();
+      out.posblock.resize(base[g] + (size_t)h->gnblk[g], -1);
+    }
+    size_t blk = 0;
+    for (int j = 0; j < nCams; j++)
+      for (int k = 0; k <= j; k++, blk++) out.posblock[base[grp_of_blk[blk]] + (size_t)out.blockpos[blk]] = (j << 16) | k;
   }
 
   // ---- workgroups: about one per CU, shared between the groups in proportion to their items ----
@@ -129,6 +154,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     const long long cap = total_items / 512;  // small problems: no point in near-empty workgroups
     if (cap < nWg) nWg = (int)(cap < G ? G : cap);
     if (nWg >= 16) nWg -= nWg % 8;
+    if (nWg < G) nWg = G;  // every group needs one
   }
   std::vector<int> gnwg((size_t)G, 1);
   {
@@ -157,9 +183,11 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   std::vector<std::vector<Raw>> raw((size_t)G);
   for (int g = 0; g < G; g++) raw[g].reserve((size_t)gitems[g]);
   for (int a = 0; a < nObs; a++) {
-    const int ja = jidx[a], i = iidx[a], g = grp_of_cam[ja];
-    for (int b = ptr[i]; b <= a; b++)
-      raw[g].push_back({a, i, a - b, out.blockpos[(size_t)(tri(ja) + jidx[b])]});
+    const int ja = jidx[a], i = iidx[a];
+    for (int b = ptr[i]; b <= a; b++) {
+      const size_t blk = (size_t)(tri(ja) + jidx[b]);
+      raw[grp_of_blk[blk]].push_back({a, i, a - b, out.blockpos[blk]});
+    }
   }
   struct WgTmp { SchurWg w; double where; };
   std::vector<WgTmp> wgs;
@@ -174,8 +202,8 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       w.slab_off = h->gslab[g] + (size_t)k * 36 * h->gnblk[g];
       w.obs0 = r1 > r0 ? raw[g][r0].a : 0;
       w.pt0 = r1 > r0 ? raw[g][r0].i : 0;
-      if (r1 > r0 && (raw[g][r1 - 1].a - w.obs0 >= (1 << 18) || raw[g][r1 - 1].i - w.pt0 >= (1 << 16))) {
-        h->nGroups = 0;  // the item encoding does not hold this range: atomic kernel instead
+      if (r1 > r0 && (raw[g][r1 - 1].a - w.obs0 >= (1 << ITEM_OBS_BITS) || raw[g][r1 - 1].i - w.pt0 >= (1 << ITEM_PT_BITS))) {
+        h->nGroups = 0;  // the item encoding does not hold this range: owner route instead
         return PSBA_OK;
       }
       // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
@@ -187,9 +215,9 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       for (size_t t = r0; t < r1; t++) {
         const Raw &it = raw[g][t];
         const unsigned long long enc = (unsigned long long)(it.a - w.obs0) |
-                                       ((unsigned long long)(it.i - w.pt0) << 18) |
-                                       ((unsigned long long)it.boff << 34) |
-                                       ((unsigned long long)it.pos << 45);
+                                       ((unsigned long long)(it.i - w.pt0) << ITEM_OBS_BITS) |
+                                       ((unsigned long long)it.boff << (ITEM_OBS_BITS + ITEM_PT_BITS)) |
+                                       ((unsigned long long)it.pos << (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
         const uint16_t bit = (uint16_t)(1u << (it.pos % ROW));
         size_t r = closed;
         while (r < mask.size() && (fill[r] == ROW || (mask[r] & bit))) r++;

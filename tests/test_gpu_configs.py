@@ -174,18 +174,23 @@ def test_levmar_on_the_other_bundled_sets(cams, pts, gpu):
     assert abs(ex @ ex - res.final_err) <= 1e-9 * res.final_err + 1e-14 * ores.init_err
 
 
-@pytest.mark.parametrize("n_cams,k1_global,k2_path", [(250, False, 0), (340, False, 1), (455, False, 1), (460, True, 1)])
-def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global, k2_path):
+@pytest.mark.parametrize("n_cams,k1_global,force_owner",
+                         [(250, False, False), (340, False, False), (340, False, True), (455, False, True),
+                          (460, True, False), (700, True, False)])
+def test_camera_counts_around_the_k1_limit(gpu, monkeypatch, n_cams, k1_global, force_owner):
     """Up to 455 cameras K1 keeps its 27 per-camera sums in LDS (more than 64 KiB of dynamic LDS
-    from ~270 cameras on), beyond that a camera-major pass forms them; K2 splits S into up to 128
-    LDS-sized camera-row groups (250 cameras: 56 groups) and takes the owner route beyond
-    (psba_schur_path says which).  S / ea / U / g against the oracle, the solve against LAPACK on
-    the oracle's S."""
+    from ~270 cameras on), beyond that a camera-major pass forms them; K2 splits S into LDS-sized
+    groups of blocks -- whole camera rows while 128 groups suffice (250 cameras: 56 groups), ranges of
+    the canonical block order beyond (460 cameras: 195 groups; from ~550 cameras on a camera row alone
+    outgrows a partition) -- or takes the owner route (forced here; psba_schur_path says which).
+    S / ea / U / g against the oracle, the solve against LAPACK on the oracle's S."""
     import psba_amd.synth as synth
     prob = synth.make_problem(n_cams=n_cams, n_pts=4000, mean_track=6.0, seed=7 + n_cams)
     o = Oracle(prob)
+    if force_owner:
+        monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
     gpu.upload_problem(prob)
-    assert gpu.schur_path() == k2_path
+    assert gpu.schur_path() == (1 if force_owner else 0)
     lin = o.linearize()
     close(gpu.compute_U(1.0), lin["U"], 1e-11, "U")
     close(gpu.compute_V(1.0), lin["V"], 1e-11, "V")
@@ -201,8 +206,8 @@ def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global, k2_path):
     ref = np.linalg.solve(sch["S"], sch["eab"][: o.nA])
     close(dpa, ref, 1e-8, "dpa")
     gpu.restore_UVdiag()
-    # the mirror verbs above dump Y / V^-1 and therefore run the first-generation atomic kernel;
-    # the fused verb runs the owner route: same S / ea through the reduce buffer
+    # the mirror verbs above dump Y / V^-1 (on the owner route through the first-generation atomic
+    # kernel); the fused verb runs the route proper: same S / ea through the reduce buffer
     gpu.linearize(1.0, 1.0)
     gpu.schur_assemble(mu)
     n32 = (o.nA + 31) // 32 * 32
@@ -216,7 +221,7 @@ def test_camera_counts_around_the_k1_limit(gpu, n_cams, k1_global, k2_path):
     assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
 
 
-def test_cfg5_scaled_two_thousand_cameras(gpu):
+def test_cfg5_scaled_two_thousand_cameras(gpu, monkeypatch):
     """BASELINE configs[4] with the point count scaled down (2000 cameras x 20 000 points x
     200 000 observations; synth.cfg5, seed 0x5BA5): the 12 000 x 12 000 dense S goes through the
     unfused MFMA panel chain.  The oracle's dense solve would take minutes at this size, so the
@@ -227,7 +232,7 @@ def test_cfg5_scaled_two_thousand_cameras(gpu):
     assert (prob["nC"], prob["nO"]) == (2000, 200000)
     o = Oracle(prob)
     gpu.upload_problem(prob)
-    assert gpu.schur_path() == 1
+    assert gpu.schur_path() == 0  # 3680 LDS partitions, one workgroup each
     lin = o.linearize()
     close(gpu.compute_U(1.0), lin["U"], 1e-11, "U")
     close(gpu.compute_g(1.0), lin["g"], 1e-11, "g")
@@ -241,14 +246,21 @@ def test_cfg5_scaled_two_thousand_cameras(gpu):
     assert np.abs(S - S.T).max() <= 1e-14 * np.abs(S).max()
     rc, dpa = gpu.SPDinv_matVec()
     assert rc == 0
-    # (the mirror verbs ran the atomic kernel: they dump Y; the owner route through the fused verb)
+    # the fused verb, and the owner route (what the full-size cfg5 takes: its 20 M observations are
+    # beyond the item fields of the LDS schedule) through the fused verb
     gpu.restore_UVdiag()
-    gpu.linearize(1.0, 1.0)
-    gpu.schur_assemble(mu)
-    M = gpu.get_reduce_buffer().reshape(o.nA + 1, o.nA)  # 12000 is a multiple of 32: no padding
-    close(M[: o.nA], sch["S"], 1e-11, "S (owner route)")
-    close(M[o.nA], sch["eab"][: o.nA], 1e-10, "ea (owner route)")
-    del M
+    for owner in (False, True):
+        if owner:
+            monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
+            gpu.upload_problem(prob)
+            assert gpu.schur_path() == 1
+            monkeypatch.delenv("PSBA_SCHUR_OWNER")
+        gpu.linearize(1.0, 1.0)
+        gpu.schur_assemble(mu)
+        M = gpu.get_reduce_buffer().reshape(o.nA + 1, o.nA)  # 12000 is a multiple of 32: no padding
+        close(M[: o.nA], sch["S"], 1e-11, f"S (fused verb, owner={owner})")
+        close(M[o.nA], sch["eab"][: o.nA], 1e-10, f"ea (fused verb, owner={owner})")
+        del M
     r = S @ dpa - ea
     scale = np.abs(S).sum(axis=1).max() * np.abs(dpa).max() + np.abs(ea).max()  # inf-norms
     assert np.abs(r).max() <= 1e-12 * scale, np.abs(r).max() / scale
@@ -314,13 +326,16 @@ def test_two_level_blocked_panel_chain(monkeypatch, n_cams):
     h.close()
 
 
-def test_single_rank_communicator_with_many_cameras(problems):
-    """The RCCL path on the many-camera routes (K1's camera-major pass, K2's owner route, the
-    all-reduce of the whole padded [S | ea] square instead of the packed triangle): results must
-    not change against a handle without a communicator."""
+@pytest.mark.parametrize("force_owner", [True, False])
+def test_single_rank_communicator_with_many_cameras(problems, monkeypatch, force_owner):
+    """The RCCL path on the many-camera routes (K1's camera-major pass; K2's owner route with the
+    all-reduce of the whole padded [S | ea] square, or block-range LDS groups with the packed
+    triangle): results must not change against a handle without a communicator."""
     import psba_amd
     import psba_amd.synth as synth
     prob = synth.make_problem(n_cams=460, n_pts=3000, mean_track=5.0, seed=991)
+    if force_owner:
+        monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
     ref = psba_amd.Psba(0)
     ref.upload_problem(prob)
     want, _ = ref.levmar(max_iter=4, tr_handoff=False)
@@ -328,7 +343,7 @@ def test_single_rank_communicator_with_many_cameras(problems):
     h = psba_amd.Psba(0)
     h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
     h.upload_problem(prob)
-    assert h.schur_path() == 1
+    assert h.schur_path() == (1 if force_owner else 0)
     res, _ = h.levmar(max_iter=4, tr_handoff=False)
     assert res.iters == want.iters
     assert abs(res.final_err - want.final_err) <= 1e-10 * want.final_err

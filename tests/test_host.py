@@ -84,7 +84,7 @@ def test_partition_more_ranks_than_points():
 
 def _check_plan(nC, nP, iidx, jidx):
     """Every product (a, b <= a, same point) appears exactly once, in the workgroup list of its
-    camera-row group, at its block's position; in a row of 16 item slots no LDS bank pair is
+    block's group, at its block's position; in a row of 16 item slots no LDS bank pair is
     hit more than twice; workgroup lists are equally long within a group."""
     from psba_amd import capi
     plan = capi.schur_plan(nC, nP, iidx, jidx)
@@ -94,7 +94,7 @@ def _check_plan(nC, nP, iidx, jidx):
     tri = lambda j: j * (j + 1) // 2
     # block positions: a bijection into the padded partition of the block's group
     for g in range(plan["groups"]):
-        b0, b1 = tri(int(glo[g])), tri(int(glo[g + 1]))
+        b0, b1 = int(glo[g]), int(glo[g + 1])
         ps = pos[b0:b1]
         assert len(set(ps.tolist())) == b1 - b0 and ps.min() >= 0
         nblk = {int(w[1]) for w in wg if w[0] == g}
@@ -107,10 +107,10 @@ def _check_plan(nC, nP, iidx, jidx):
         slabs.add((g, slab))
         it = items[s0:s1]
         live = it != np.uint64(0xFFFFFFFFFFFFFFFF)
-        a = obs0 + (it & np.uint64(0x3FFFF)).astype(np.int64)
-        i = pt0 + ((it >> np.uint64(18)) & np.uint64(0xFFFF)).astype(np.int64)
-        boff = ((it >> np.uint64(34)) & np.uint64(0x7FF)).astype(np.int64)
-        p = ((it >> np.uint64(45)) & np.uint64(0x3FF)).astype(np.int64)
+        a = obs0 + (it & np.uint64(0x3FFFFF)).astype(np.int64)          # 22 bits
+        i = pt0 + ((it >> np.uint64(22)) & np.uint64(0x1FFFFF)).astype(np.int64)  # 21 bits
+        boff = ((it >> np.uint64(43)) & np.uint64(0x7FF)).astype(np.int64)
+        p = ((it >> np.uint64(54)) & np.uint64(0x3FF)).astype(np.int64)
         for r in range(0, len(it), 16):
             q = p[r:r + 16][live[r:r + 16]] % 16
             assert np.bincount(q, minlength=16).max() <= 2  # a bank pair at most twice per row
@@ -118,8 +118,9 @@ def _check_plan(nC, nP, iidx, jidx):
         b = a - boff
         assert (iidx[a] == i).all() and (iidx[b] == i).all() and (b >= ptr[i]).all()
         ja, jb = jidx[a].astype(np.int64), jidx[b].astype(np.int64)
-        assert ((ja >= glo[g]) & (ja < glo[g + 1])).all()
-        assert (pos[ja * (ja + 1) // 2 + jb] == p).all()
+        blk = ja * (ja + 1) // 2 + jb
+        assert ((blk >= glo[g]) & (blk < glo[g + 1])).all()
+        assert (pos[blk] == p).all()
         keys = set(zip(a.tolist(), b.tolist()))
         assert len(keys) == len(a) and not (keys & seen)
         seen |= keys
@@ -145,6 +146,19 @@ def test_schur_plan_venice_shaped():
     # the bank-pair schedule should cost little padding on a realistic problem
     assert plan["products"] / len(plan["items"]) > 0.75
     assert len(plan["wg"]) == 256
+
+
+@pytest.mark.parametrize("n_cams", [300, 700])
+def test_schur_plan_many_cameras(n_cams):
+    """Beyond the row-aligned groups (more than 128 of them, or a camera row longer than an LDS
+    partition) the groups are consecutive ranges of the canonical block order, one workgroup each."""
+    from psba_amd import synth
+    pr = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=11)
+    plan = _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+    assert len(plan["wg"]) >= plan["groups"] and (plan["groups"] > 128 or n_cams < 500)
+    glo = plan["glo"]
+    assert glo[0] == 0 and glo[-1] == n_cams * (n_cams + 1) // 2 and (np.diff(glo) > 0).all()
+    assert np.diff(glo).max() * 37 * 8 <= 160 * 1024 - 256
 
 
 def test_writer_round_trip(tmp_path):
