@@ -32,6 +32,20 @@ namespace psba {
 
 // diag: factor the block at (j, j) in place and store the inverse of its factor.  Launched
 // alone only for the first panel.
+// a 32x32 block (row stride `rs` doubles) into LDS with 256 threads: the four loads of a thread
+// first, then the four stores.  Written as `for (t = tid; t < 1024; t += 256) dst[..] = src[..]`
+// the loop is not unrolled and every load is waited for before the next is issued (4 dependent
+// global latencies instead of one).
+template <class Arr>
+__device__ __forceinline__ void stage_block32(Arr &dst, const double *src, size_t rs, int tid) {
+  const int r = tid / GB, c = tid % GB;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) v[q] = src[(size_t)(r + 8 * q) * rs + c];
+#pragma unroll
+  for (int q = 0; q < 4; q++) dst[r + 8 * q][c] = v[q];
+}
+
 __global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx, int ld, int j, double *linv,
                                                     int *status, long long *tim) {
   __shared__ Factor32Lds s;
@@ -39,7 +53,7 @@ __global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx
   if (tid < 4) s.flag[tid] = 0;
   if (tid == 4) s.fail = 0;
   if (tim && tid == 0) tim[0] = (long long)__builtin_amdgcn_s_memtime();
-  for (int t = tid; t < GB * GB; t += 256) s.D[t / GB][t % GB] = Lw[(size_t)(j + t / GB) * ld + j + t % GB];
+  stage_block32(s.D, Lw + (size_t)j * ld + j, (size_t)ld, tid);
   __syncthreads();
   if (tim && tid == 0) tim[1] = (long long)__builtin_amdgcn_s_memtime();
   factor32(s, tid, tim);
@@ -481,7 +495,9 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
 // two kernels this saves a kernel boundary and a global round trip of X per panel; the redundant
 // MFMA work runs in the shadow of workgroup 0's serial factorization.
 constexpr int XS = 34;  // row stride of the X scratch: 16-byte aligned rows, conflict-free pieces
-__global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT,
+// nId: identity tile rows that ride along (T0 in the fused chain, whose solve is a product with the
+// transformed identity rows; 0 in the mid-size chain, which solves backward through the factor).
+__global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT, int nId,
                                                      double *linv, int *status) {
   __shared__ Factor32Lds s;
   __shared__ double sX[4][2][16][XS];
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
   }
   int TR, TC;
   bool fresh;
-  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, T0, TR, TC, fresh)) return;
+  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, nId, TR, TC, fresh)) return;
   d4 c = {0, 0, 0, 0};
   if (!fresh) c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
   d4 xl, xr;
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(256) void k_cholg_back_panel(double *Lw /* the fact
   const int tid = threadIdx.x;
   double *y = Lw + (size_t)n32 * ld;
   const double *Li = linv + (size_t)(j / GB) * GB * GB;
-  for (int t = tid; t < GB * GB; t += 256) sLi[t / GB][t % GB] = Li[t];
+  stage_block32(sLi, Li, GB, tid);
   if (tid < GB) sY[tid] = y[j + tid];
   __syncthreads();
   if (tid < GB) {
@@ -657,6 +673,99 @@ __global__ __launch_bounds__(256) void k_cholg_back_panel(double *Lw /* the fact
   y[c] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
 }
 
+// The same with up to four 32-column blocks per launch (columns [j0, j0 + 32 nb), last block first):
+// every workgroup walks the small triangular part for itself -- x_b = L_bb^-T y_b, then
+// y_b' -= L[b][b']^T x_b for the blocks b' < b of the launch, kept in LDS, never written back -- and
+// then applies all 32 nb rows at once to its columns c < j0.  A launch costs ~5 us whatever it
+// does, so four blocks per launch take the backward solve from 4.6 to ~2 us per block.
+constexpr int BACK_NB = 4;
+__global__ __launch_bounds__(256) void k_cholg_back_multi(double *Lw /* the factor buffer */, int ld, int n, int n32,
+                                                          int j0, int nb, double *x, const double *linv, int *status) {
+  // everything the serial part reads is fetched up front (the addresses depend on nothing computed
+  // here): the nb inverse diagonal blocks and the nb (nb - 1) / 2 blocks L[b][b'] between them
+  __shared__ double sLi[BACK_NB][GB][GB + 1];
+  __shared__ double sL[BACK_NB * (BACK_NB - 1) / 2][GB][GB + 1];
+  __shared__ double sY[BACK_NB * GB], sX[BACK_NB * GB], sQ[8][GB], sQ2[2][128];
+  const int tid = threadIdx.x;
+  double *y = Lw + (size_t)n32 * ld;
+  // (all loads first, into registers, then the LDS stores: written as load-store loops the compiler
+  // waits for every load before the next one -- 13 us of the kernel's 17)
+  double vLi[BACK_NB][4], vL[BACK_NB * (BACK_NB - 1) / 2][4];
+  const int tr = tid / GB, tc = tid % GB;  // element (tr + 8 q, tc) of a 32x32 block, q = 0..3
+#pragma unroll
+  for (int b = 0; b < BACK_NB; b++) {
+    const double *Li = linv + (size_t)(j0 / GB + (b < nb ? b : 0)) * GB * GB;
+#pragma unroll
+    for (int q = 0; q < 4; q++) vLi[b][q] = Li[tid + 256 * q];
+#pragma unroll
+    for (int bp = 0; bp < b; bp++) {
+      const double *L = Lw + (size_t)(j0 + (b < nb ? b : 0) * GB) * ld + j0 + bp * GB;
+#pragma unroll
+      for (int q = 0; q < 4; q++) vL[b * (b - 1) / 2 + bp][q] = L[(size_t)(tr + 8 * q) * ld + tc];
+    }
+  }
+  const double vy = tid < nb * GB ? y[j0 + tid] : 0.0;
+  // 64 columns c < j0 per workgroup, wave w applies block w's 32 rows to them: all of a thread's
+  // loads are in flight during the serial part (their addresses depend on nothing computed here)
+  __shared__ double sP[BACK_NB][64];
+  const int w = tid >> 6, lane = tid & 63;
+  const int c = blockIdx.x * 64 + lane;
+  const bool mine = c < j0 && w < nb;
+  const double *L = Lw + (size_t)(j0 + w * GB) * ld + (mine ? c : 0);
+  double pre[GB];
+#pragma unroll
+  for (int r = 0; r < GB; r++) pre[r] = mine ? L[(size_t)r * ld] : 0.0;
+  if (tid < nb * GB) sY[tid] = vy;
+#pragma unroll
+  for (int b = 0; b < BACK_NB; b++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) sLi[b][tr + 8 * q][tc] = vLi[b][q];
+#pragma unroll
+    for (int bp = 0; bp < b; bp++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) sL[b * (b - 1) / 2 + bp][tr + 8 * q][tc] = vL[b * (b - 1) / 2 + bp][q];
+  }
+  __syncthreads();
+  for (int b = nb - 1; b >= 0; b--) {
+    {  // (L_bb^-T y_b)[c] = sum_r Linv[r][c] y_b[r]: eight threads per column, four rows each
+      const int cc = tid & 31, pp = tid >> 5;
+      const double q0 = sLi[b][4 * pp][cc] * sY[b * GB + 4 * pp], q1 = sLi[b][4 * pp + 1][cc] * sY[b * GB + 4 * pp + 1];
+      const double q2 = sLi[b][4 * pp + 2][cc] * sY[b * GB + 4 * pp + 2], q3 = sLi[b][4 * pp + 3][cc] * sY[b * GB + 4 * pp + 3];
+      sQ[pp][cc] = (q0 + q1) + (q2 + q3);
+    }
+    __syncthreads();
+    if (tid < GB) {
+      const double v = ((sQ[0][tid] + sQ[1][tid]) + (sQ[2][tid] + sQ[3][tid])) + ((sQ[4][tid] + sQ[5][tid]) + (sQ[6][tid] + sQ[7][tid]));
+      sX[b * GB + tid] = v;
+      if (blockIdx.x == 0) {
+        if (j0 + b * GB + tid < n) x[j0 + b * GB + tid] = v;
+        if (!isfinite(v)) status[1] = status[3];
+      }
+    }
+    __syncthreads();
+    {  // the launch's own blocks to the left: y_b'[c] -= sum_r L[b][b'][r][c] x_b[r], two threads per entry
+      const int o = tid & 127, half = tid >> 7;
+      if (o < b * GB) {
+        const int bp = o / GB, cc = o % GB;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < GB / 2; r++)
+          a4[r & 3] += sL[b * (b - 1) / 2 + bp][GB / 2 * half + r][cc] * sX[b * GB + GB / 2 * half + r];
+        sQ2[half][o] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      }
+    }
+    __syncthreads();
+    if (tid < b * GB) sY[tid] -= sQ2[0][tid] + sQ2[1][tid];
+    __syncthreads();
+  }
+  double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < GB; r++) a4[r & 3] += pre[r] * sX[(w < nb ? w : 0) * GB + r];
+  sP[w][lane] = mine ? (a4[0] + a4[1]) + (a4[2] + a4[3]) : 0.0;
+  __syncthreads();
+  if (w == 0 && c < j0) y[c] -= (sP[0][lane] + sP[1][lane]) + (sP[2][lane] + sP[3][lane]);
+}
+
 // dpa = L^-T y: the identity rows of the factor buffer hold L^-T (row i = e_i^T L^-T, upper
 // triangular) for all panels but the last, y = L^-1 e_a sits in row n32.  One wave per row, all
 // loads of a lane issued at once (n32 <= 640 on this path: at most ten 64-column strides).
@@ -670,7 +779,7 @@ __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const dou
   const int tid = threadIdx.x, lane = tid & 63, i = blockIdx.x * 4 + (tid >> 6);
   const int jl = n32 - GB;  // first column of the last panel
   const double *Li = linv + (size_t)(jl / GB) * GB * GB;
-  for (int t = tid; t < GB * GB; t += 256) sLi[t / GB][t % GB] = Li[t];
+  stage_block32(sLi, Li, GB, tid);
   const double rk = tid < GB ? Lw[(size_t)n32 * ld + jl + tid] : 0.0;
   // the main part of the row's sum is in flight while w is formed
   const bool row = i < n;
@@ -729,7 +838,15 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   int NB = 256;  // super-panel width of the two-level chain: 64 / 128 / 256 / 512 -> 32.0 / 28.0 / 26.0 / 25.6 ms at n = 12000 (PSBA_CHOL_NB: development knob, multiple of 32)
   if (const char *e = getenv("PSBA_CHOL_NB")) NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : NB;
-  const bool blocked = !fused && (n32 >= 4096 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
+  // (measured, 6-iteration LM runs: n = 2400 flat 1348 us / two-level 1431; n = 3600 2622 / 2329)
+  const bool blocked = !fused && (n32 >= 3072 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
+  // mid sizes: the fused panel kernel without the identity rows (one kernel per panel instead of
+  // trsm + update: the redundant X pieces cost less than the second launch while the panel has few
+  // tiles; per solve n = 600: 218 against 267 us, 780: 292 / 356, 1200: 502 / 564, 1542: 763 / 759,
+  // 2040: 1241 / 1070), backward solve through the factor
+  long long f2max = 3600;
+  if (const char *e = getenv("PSBA_CHOL_FUSED2_MAX")) f2max = atoll(e);
+  const bool fused2 = !fused && !blocked && M0 * (M0 + 1) / 2 <= f2max;
   for (int J = 0; blocked && J < n32; J += NB) {
     const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
     for (int j = J; j < JE; j += GB) {
@@ -762,7 +879,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     const int T0 = (j + GB) / 16;
     const long long M = (nT - 1) - T0;
     if (last && fused) break;  // the last panel's trsm is part of k_cholg_solve
-    if (last || !fused) {
+    if (last || !(fused || fused2)) {
       // 16-row tiles below the panel incl. the e_a tile
       const int nTall = nT;
       hipLaunchKernelGGL(k_cholg_trsm, dim3((nTall - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nTall, linv);
@@ -771,19 +888,31 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
         hipLaunchKernelGGL(k_cholg_update, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
       }
     } else {
-      const int grid = 1 + (int)((M * (M + 1) / 2 + M + (long long)T0 * M - 3 + 3) / 4);
-      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, linv, h->status);
+      const int nId = fused ? T0 : 0;
+      const int grid = 1 + (int)((M * (M + 1) / 2 + M + (long long)nId * M - 3 + 3) / 4);
+      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, nId, linv, h->status);
     }
   }
   if (fused) {
     hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
                        linv, h->status);
   } else {
-    if (n32 > 2048 || getenv("PSBA_CHOL_BACK_PANELS")) {
-      // large matrices: one small kernel per block, all CUs (see k_cholg_back_panel)
-      for (int j = n32 - GB; j >= 0; j -= GB)
-        hipLaunchKernelGGL(k_cholg_back_panel, dim3(j / 256 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j, h->dp,
-                           linv, h->status);
+    if (!getenv("PSBA_CHOL_BACK_ONE_WG")) {
+      // one small kernel per block, all CUs (see k_cholg_back_panel); against one workgroup walking
+      // the factor (k_cholg_backward, kept for comparison): n = 780 356 / 385 us per solve, 1542
+      // 760 / 1071, 2040 1071 / 1695
+      if (getenv("PSBA_CHOL_BACK_SINGLE")) {  // one block per launch (kept for comparison)
+        for (int j = n32 - GB; j >= 0; j -= GB)
+          hipLaunchKernelGGL(k_cholg_back_panel, dim3(j / 256 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j, h->dp,
+                             linv, h->status);
+      } else {
+        for (int R = n32 / GB; R > 0;) {
+          const int nb = R < BACK_NB ? R : BACK_NB, j0 = (R - nb) * GB;
+          hipLaunchKernelGGL(k_cholg_back_multi, dim3(j0 / 64 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j0, nb,
+                             h->dp, linv, h->status);
+          R -= nb;
+        }
+      }
     } else {
       int thr = (n32 + 63) / 64 * 64;
       if (thr > 512) thr = 512;

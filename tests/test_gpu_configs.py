@@ -272,12 +272,15 @@ def test_cfg5_scaled_two_thousand_cameras(gpu, monkeypatch):
     assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
 
 
-def test_panelwise_backward_solve(monkeypatch):
-    """PSBA_CHOL_BACK_PANELS=1 forces the backward solve large matrices take (one kernel per
-    32-column block over all CUs, k_cholg_back_panel) at a size the oracle solves quickly."""
+@pytest.mark.parametrize("one_wg", [False, True])
+def test_backward_solve_variants(monkeypatch, one_wg):
+    """The backward solve of the unfused chains: one kernel per 32-column block over all CUs
+    (k_cholg_back_panel, the default) and one workgroup walking the factor (k_cholg_backward,
+    PSBA_CHOL_BACK_ONE_WG=1, kept for comparison), at a size the oracle solves quickly."""
     import psba_amd
     import psba_amd.synth as synth
-    monkeypatch.setenv("PSBA_CHOL_BACK_PANELS", "1")
+    if one_wg:
+        monkeypatch.setenv("PSBA_CHOL_BACK_ONE_WG", "1")
     prob = synth.make_problem(n_cams=130, n_pts=3000, mean_track=5.0, seed=77)
     o = Oracle(prob)
     lin = o.linearize()
