@@ -719,8 +719,10 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   int most = 1;
   for (int g = 0; g < h->nGroups; g++) most = h->gnwg[g] > most ? h->gnwg[g] : most;
   r.grp16 = h->gtab;
-  r.chunks = most > 16 ? 1 : most > 8 ? 2 : most > 4 ? 4 : 8;  // up to four slabs: a thread sums them alone
-  if (const char *e = getenv("PSBA_REDUCE_CHUNKS")) r.chunks = atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8 ? atoi(e) : 1;
+  // up to four slabs: a thread sums them alone (8 chunks, no exchange); else 4 chunks x 2 sequences
+  // (venice-shaped, ~85 slabs per group: 10.2 / 9.0 / 8.8 / 10.8 us with 1 / 2 / 4 / 8 chunks)
+  r.chunks = most > 4 ? 4 : 8;
+  if (const char *e = getenv("PSBA_REDUCE_CHUNKS")) r.chunks = atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8 ? atoi(e) : 1;  // development knob
   r.nchunks = 36 * npos / 64;  // partitions are multiples of 16 blocks = 9 x 64 doubles
   const int rgrid = (int)((r.nchunks + r.chunks - 1) / r.chunks);
   r.diag_wg = fuse_diag ? rgrid : -1;
