@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
 constexpr int XS = 34;  // row stride of the X scratch: 16-byte aligned rows, conflict-free pieces
 // nId: identity tile rows that ride along (T0 in the fused chain, whose solve is a product with the
 // transformed identity rows; 0 in the mid-size chain, which solves backward through the factor).
-__global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT, int nId,
+// TE >= 0: the 32-column step inside a super-panel of the two-level chain -- only the tiles of the
+// tile columns [T0, TE), all rows below (as k_cholg_update_cols, whose trsm kernel this saves).
+__global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT, int nId, int TE,
                                                      double *linv, int *status) {
   __shared__ Factor32Lds s;
   __shared__ double sX[4][2][16][XS];
@@ -544,8 +546,20 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     return;
   }
   int TR, TC;
-  bool fresh;
-  if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, nId, TR, TC, fresh)) return;
+  bool fresh = false;
+  if (TE >= 0) {
+    long long idx = (long long)(blockIdx.x - 1) * 4 + wave;
+    TC = T0;
+    while (TC < TE && idx >= nT - TC) {
+      idx -= nT - TC;
+      TC++;
+    }
+    if (TC >= TE) return;
+    TR = TC + (int)idx;
+    if (TR <= T0 + 1 && TC <= T0 + 1) return;  // workgroup 0's three tiles (and the unused (T0, T0+1))
+  } else if (!tile_of_index((long long)(blockIdx.x - 1) * 4 + wave + 3, T0, nT, nId, TR, TC, fresh)) {
+    return;
+  }
   d4 c = {0, 0, 0, 0};
   if (!fresh) c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
   d4 xl, xr;
@@ -847,17 +861,26 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   long long f2max = 3600;
   if (const char *e = getenv("PSBA_CHOL_FUSED2_MAX")) f2max = atoll(e);
   const bool fused2 = !fused && !blocked && M0 * (M0 + 1) / 2 <= f2max;
+  long long cols_fused_max = 3000;  // sweep 0 / 3000 / 6000 / 9000 tiles: n = 6000 4.77 / 4.56 / 4.72 / 4.69 ms per LM iteration, n = 12 000 17.85 / 17.63 / 18.19 / 18.80 ms per solve
+  if (const char *e = getenv("PSBA_CHOL_COLS_FUSED_MAX")) cols_fused_max = atoll(e);
   for (int J = 0; blocked && J < n32; J += NB) {
     const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
     for (int j = J; j < JE; j += GB) {
       const int T0 = (j + GB) / 16, TE = JE / 16;
+      long long tiles = 0;  // tiles of the super-panel's remaining columns, all rows below
+      for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
+      if (j + GB < JE && tiles <= cols_fused_max) {
+        // trsm + update in one kernel (every wave forms the X pieces of its tile itself: 40 MFMAs
+        // per tile instead of 8, which pays while the step has few tiles -- per LM iteration
+        // n = 3600: 2.17 against 2.36 ms, 6000: 4.72 / 4.78, 12 000 (all steps): 19.0 / 17.9)
+        hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nT, 0,
+                           TE, linv, h->status);
+        continue;
+      }
       hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
-      if (j + GB < JE) {  // tiles of the super-panel's remaining columns, all rows below
-        long long tiles = 0;
-        for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
+      if (j + GB < JE)
         hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
                            nT, TE, linv, h->status);
-      }
     }
     if (JE < n32) {
       const int Tw = JE / 16;
@@ -890,7 +913,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     } else {
       const int nId = fused ? T0 : 0;
       const int grid = 1 + (int)((M * (M + 1) / 2 + M + (long long)nId * M - 3 + 3) / 4);
-      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, nId, linv, h->status);
+      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, nId, -1, linv, h->status);
     }
   }
   if (fused) {
