@@ -122,11 +122,11 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
     if (sEa[t] != 0.0) atomicAdd(&p.ea[t], sEa[t]);
 }
 
-// v4: the lower block triangle of S is split into camera-row groups whose 6x6 accumulators fit
-// in LDS, and a static schedule built at upload time (schur_plan.cpp) gives every workgroup an
+// v4: the lower block triangle of S is split into groups of blocks (whole camera rows, or ranges
+// of the canonical block order for many cameras) whose 6x6 accumulators fit in LDS, and a static schedule built at upload time (schur_plan.cpp) gives every workgroup an
 // equally long list of self-contained 64-bit work items, one per product Y_a W_b^T (b <= a,
 // same point), point-major so that neighbouring lanes read the same W rows:
-//   bits 0..17 a - obs0   18..33 i - pt0   34..44 a - b   45..54 block position in the partition
+//   bits 0..21 a - obs0   22..42 i - pt0   43..53 a - b   54..63 block position in the partition
 // One item per thread: all loads of the product are issued at once, V*^-1 and Y_a are formed
 // in registers and the 6x6 product is added into the LDS partition with ds_add_f64.
 //  * blocks sit at a stride of 37 doubles and the schedule deals items into rows of 16 lanes
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
 //    slots carry the e_a term  -Y_a g_b,i  instead: no separate e_a accumulators or atomics;
 //  * the partition is written once, as plain stores, into the workgroup's slab;
 //    k_schur_reduce sums the slabs of a group in a fixed order;
-//  * workgroups that work on the same stretch of points (for different camera-row groups)
+//  * workgroups that work on the same stretch of points (for different groups of blocks)
 //    are mapped to the same XCD (blockIdx % 8) so that the re-reads of W are L2 hits.
 constexpr int SCHUR_THREADS = 1024;
 constexpr int BLK_STRIDE = 37;
@@ -324,7 +324,7 @@ struct SchurReduceArgs {
   double *packed;
 };
 
-// sums the slabs of each camera-row group (fixed order: eight interleaved slab sequences, then
+// sums the slabs of each group of blocks (fixed order: eight interleaved slab sequences, then
 // their sum), adds blockdiag(U) + mu_add I and g_a, and writes the padded row-major S (both
 // block triangles) and the e_a row.  Workgroups walk the slabs in storage order (32
 // consecutive pairs of doubles x 8 slab sequences each; a group's partition is a multiple of 576

@@ -329,7 +329,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->chol_L, (size_t)(2 * h->n32 + 16) * h->n32));
   PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * (size_t)(2 * h->n32 + 16) * h->n32, h->stream));
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
-  // ---- K2's static schedule (camera-row groups, workgroups, conflict-free item rows) ----
+  // ---- K2's static schedule (groups of blocks, workgroups, conflict-free item rows) ----
   {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));

@@ -42,7 +42,7 @@ struct Dims {
   int maxTrack = 0;
 };
 
-// one workgroup of k_schur_lds: a range of work items of one camera-row group
+// one workgroup of k_schur_lds: a range of work items of one group of blocks
 // item = (a - obs0) | (i - pt0) << 22 | (a - b) << 43 | position << 54: observation (22 bits), point
 // (21 bits), distance to the partner observation of the same point (11 bits), block position in the
 // partition (10 bits)

@@ -5,8 +5,9 @@
 // values is decided once, at upload time, here (the reference decides the same things per launch
 // through blkIdx_buffer look-ups in CL_files/compute_S.cl:13-22 and compute_Y.cl:14-20):
 //
-//  * S's lower block triangle is split into camera-row groups whose 6x6 accumulators fit in
-//    one workgroup's LDS;
+//  * S's lower block triangle is split into groups of blocks whose 6x6 accumulators fit in one
+//    workgroup's LDS: whole camera rows while 128 groups suffice, else consecutive ranges of the
+//    canonical block order tri(j) + k;
 //  * one work item per product (a, b), b <= a in the same point; the items of a group, in
 //    point-major order, are cut into equally long ranges, one per workgroup, and the groups get
 //    workgroups in proportion to their items -- every workgroup has the same amount of work;
@@ -46,7 +47,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   h->packedN = 36 * (size_t)total_blocks;
   h->nGroups = 0;
   if (nCams >= 2048 || getenv("PSBA_SCHUR_OWNER")) return PSBA_OK;  // item fields; PSBA_SCHUR_OWNER forces the owner route
-  // ---- camera-row groups by LDS budget: 37 doubles per block, block count padded to 16 ----
+  // ---- row-aligned groups by LDS budget: 37 doubles per block, block count padded to 16 ----
   // 100 KiB rather than all 160: smaller partitions mean less slab traffic (flush + reduce),
   // which on venice-shaped outweighs the loss of locality from more groups (scripts/k2_lds_sweep.sh)
   // (many cameras: the whole LDS rather than giving up on the schedule)
@@ -245,7 +246,7 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     }
   }
   // workgroups ordered by where in the point sequence they work: neighbours (which re-read the
-  // same W rows for different camera-row groups) land on the same XCD, see k_schur_lds
+  // same W rows for different groups) land on the same XCD, see k_schur_lds
   std::stable_sort(wgs.begin(), wgs.end(), [](const WgTmp &x, const WgTmp &y) { return x.where < y.where; });
   out.wgs.clear();
   for (auto &t : wgs) out.wgs.push_back(t.w);
