@@ -27,12 +27,17 @@ struct BackArgs {
   double *dbg_eb;
   const int *status;   // [0] singular-V stamp, [1] not-SPD stamp, [3] this try's stamp
   double mu;
+  double coeff;        // W_ij = coeff A_ij^T B_ij (the coefficient of the linearization W came from)
   int nC, nA, nTiles;
   int cam_terms;       // 1 on the rank that owns the camera terms of the scalar sums
   int mode;            // development ablation (PSBA_BACK_MODE): 1 no residual pass, 2 no W^T dpa pass
 };
 
-template <bool DUMP>
+// RECOMP: W_ij^T dpa_j = coeff B_ij^T (A_ij dpa_j) from the Jacobian blocks recomputed at the current
+// parameters (~300 flop per observation) instead of from the stored W (144 bytes per observation:
+// 50 of the kernel's 66 MB at venice size); the camera constants and parameters loaded for it are
+// the ones the residual pass needs anyway.  (PSBA_BACK_READ_W=1: the W-reading form.)
+template <bool DUMP, bool RECOMP>
 __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
   __shared__ double sT[TILE_OBS][3];   // W_a^T dpa_j per observation
   __shared__ double sNP[TILE_OBS][3];  // proposed point per point of the tile
@@ -81,16 +86,42 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
       pb1 = p.ptr[p0 + tid + 1] - o0;
     }
     __syncthreads();
-    if (a < o1 && p.mode != 2) {
-      const double *w = p.W + 18 * (size_t)a;
-      const double *da = p.dp + 6 * j;
-      double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    double cc[9], cam[6], da[6];
+    if (RECOMP && a < o1) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        const double dk = da[k];
-        t0 += w[3 * k] * dk;
-        t1 += w[3 * k + 1] * dk;
-        t2 += w[3 * k + 2] * dk;
+        cam[k] = p.cams[6 * j + k];
+        da[k] = p.dp[6 * j + k];
+      }
+    }
+    if (a < o1 && p.mode != 2) {
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+      if (RECOMP) {
+        double M[3], e[2], A[12], B[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[k] = p.pts[3 * (size_t)i + k];
+        linearize_obs(cc, cc + 5, cam, M, 0.0, 0.0, e, A, B);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          s0 += A[k] * da[k];
+          s1 += A[6 + k] * da[k];
+        }
+        t0 = p.coeff * (B[0] * s0 + B[3] * s1);
+        t1 = p.coeff * (B[1] * s0 + B[4] * s1);
+        t2 = p.coeff * (B[2] * s0 + B[5] * s1);
+      } else {
+        const double *w = p.W + 18 * (size_t)a;
+        const double *dw = p.dp + 6 * j;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double dk = dw[k];
+          t0 += w[3 * k] * dk;
+          t1 += w[3 * k + 1] * dk;
+          t2 += w[3 * k + 2] * dk;
+        }
       }
       sT[tid][0] = t0;
       sT[tid][1] = t1;
@@ -145,11 +176,16 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     }
     __syncthreads();
     if (a < o1 && p.mode != 1) {
-      double cc[9], cam[6], e0, e1;
+      double e0, e1;
+      if (!RECOMP) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
+        for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k] + p.dp[6 * j + k];
+        for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k] + p.dp[6 * j + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cam[k] += da[k];
+      }
       const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
       residual_obs(cc, cc + 5, cam, sNP[i - p0], m.x, m.y, e0, e1);
       s_cost += e0 * e0 + e1 * e1;
@@ -200,6 +236,7 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   a.dbg_eb = h->dbg_eb;
   a.status = h->status;
   a.mu = mu;
+  a.coeff = h->coeff_w;
   a.nC = d.nC;
   a.nA = d.nA;
   a.nTiles = d.nTiles;
@@ -216,10 +253,15 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   if (const char *e = getenv("PSBA_BACK_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;
   {
     ProfScope ps(h, PSBA_K_BACKSUB);
-    if (dump)
-      hipLaunchKernelGGL(k_backsub<true>, dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+    const bool read_w = getenv("PSBA_BACK_READ_W") != nullptr;
+    if (dump && read_w)
+      hipLaunchKernelGGL((k_backsub<true, false>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+    else if (dump)
+      hipLaunchKernelGGL((k_backsub<true, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+    else if (read_w)
+      hipLaunchKernelGGL((k_backsub<false, false>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
     else
-      hipLaunchKernelGGL(k_backsub<false>, dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      hipLaunchKernelGGL((k_backsub<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

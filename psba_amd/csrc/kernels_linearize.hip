@@ -356,6 +356,7 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
   a.dbg_JA = h->dbg_JA;
   a.dbg_JB = h->dbg_JB;
   a.coeff = h->coeff;
+  h->coeff_w = h->coeff;  // K3 forms W^T dpa from the Jacobian blocks: it needs W's coefficient
   a.coeff_g = h->coeff_g;
   a.nC = d.nC;
   a.nTiles = d.nTiles;

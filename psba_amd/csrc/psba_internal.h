@@ -198,6 +198,7 @@ struct psba_ctx {
   bool backsub_pending = false;  // psba_backsub_async issued, psba_backsub_wait not yet
   int cur = 0;                  // index of the current parameter set in cams[]/pts[]
   double coeff = 1.0, coeff_g = 1.0, mu = 0.0;
+  double coeff_w = 1.0;         // the coefficient the stored W was formed with (last K1 launch)
   bool mu_applied = false;      // update_UV called (fine-grained mirror only)
 
   // ---- profiling ----
