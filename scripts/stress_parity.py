@@ -40,9 +40,19 @@ while time.time() - t0 < budget:
     _, dpo, _ = o.solve(lin, sch) if o.nA <= 1600 else (None, None, None)
     if dpo is not None:
         e["dp"] = np.abs(dp - dpo).max() / np.abs(dpo).max()
-    bad = e["S"] > 1e-11 or e["ea"] > 1e-10 or e["dpa"] > 1e-7 or e.get("dp", 0) > 1e-7 or (sc.status != 0)
+    if n % 4 == 0 and n_cams <= 200:  # the LM loop, four iterations, against the oracle's trajectory
+        h.upload_problem(prob)
+        res, log = h.levmar(max_iter=4, tr_handoff=False)
+        ores, olog = Oracle(prob).levmar(max_iter=4, tr_handoff=False)
+        acc, oacc = log[log[:, 4] > 0], olog[olog[:, 4] > 0]
+        m = min(len(acc), len(oacc))
+        e["lm"] = float(np.abs(acc[:m, 1] - oacc[:m, 1]).max() / ores.init_err) if m else 0.0
+        if len(acc) != len(oacc) or res.tries != ores.tries:
+            e["lm"] = max(e["lm"], 1.0)
+        worst["lm"] = max(worst.get("lm", 0.0), e["lm"])
+    bad = e.get("lm", 0.0) > 1e-8 or e["S"] > 1e-11 or e["ea"] > 1e-10 or e["dpa"] > 1e-7 or e.get("dp", 0) > 1e-7 or (sc.status != 0)
     for k, v in e.items():
-        worst[k] = max(worst[k], v)
+        worst[k] = max(worst.get(k, 0.0), v)
     n += 1
     if bad or n % 10 == 0:
         print(f"{'BAD ' if bad else ''}case {n}: nC={n_cams} nP={n_pts} nO={prob['nO']} path={h.schur_path()} status={sc.status} " + " ".join(f"{k}={v:.2e}" for k, v in e.items()), flush=True)
