@@ -55,10 +55,21 @@ ProfScope::~ProfScope() {
 
 // every entry point makes the handle's device current: a host may keep handles on several GPUs
 // in one process, or call from a thread whose current device is another one
-#define CHECK_H(h)                        \
+// With a communicator the try's scalar all-reduce and its copy to the host run on a side stream
+// (psba_backsub_async), beside the linearization that is queued ahead; whatever else is queued on
+// the main stream before psba_backsub_wait has returned must come after them.
+#define CHECK_H_NOJOIN(h)                 \
   do {                                    \
     if (!(h)) return PSBA_E_INVALID;      \
     (void)hipSetDevice((h)->device);      \
+  } while (0)
+#define CHECK_H(h)                                                         \
+  do {                                                                     \
+    CHECK_H_NOJOIN(h);                                                     \
+    if ((h)->scal_side) {                                                  \
+      (void)hipStreamWaitEvent((h)->stream, (h)->scal_event, 0);           \
+      (h)->scal_side = false;                                              \
+    }                                                                      \
   } while (0)
 #define NEED(h, cond, what)                                             \
   do {                                                                  \
@@ -184,7 +195,10 @@ int psba_destroy(psba_handle h) {
   CHECK_H(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->k3_event) (void)hipEventDestroy(h->k3_event);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   free_problem_buffers(h);
   dev_free(h->scal);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -594,12 +608,24 @@ int psba_backsub_async(psba_handle h, double mu) {
   CHECK_H(h);
   NEED(h, h->solved, "psba_schur_solve first");
   TRY(launch_backsub(h, mu, false));
-  if (h->comm)  // four sums (as partial sets) + two status flags in one collective
-    RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum,
-                          h->comm, h->stream));
-  PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost,
-                             h->stream));
-  PSBA_HIP(h, hipEventRecord(h->scal_event, h->stream));
+  hipStream_t s = h->stream;
+  if (h->comm) {
+    // four sums (as partial sets) + two status flags in one collective -- on the side stream, so
+    // that the linearization the loop queues next (psba_linearize_ahead) runs beside the collective
+    // and the copy instead of behind them (a small all-reduce is ~20-30 us of latency, K1 33 us)
+    // (one rank: the collective is a 5 us copy and the two event hops cost more than they hide --
+    // 0.221 against 0.213 ms per LM iteration; PSBA_COMM_SIDE_STREAM=1 forces the side stream there,
+    // which is how the tests cover it; N > 1 has not been measured)
+    if (h->stream2 && !getenv("PSBA_COMM_ONE_STREAM") && (h->nranks > 1 || getenv("PSBA_COMM_SIDE_STREAM"))) {
+      PSBA_HIP(h, hipEventRecord(h->k3_event, h->stream));
+      PSBA_HIP(h, hipStreamWaitEvent(h->stream2, h->k3_event, 0));
+      s = h->stream2;
+      h->scal_side = true;
+    }
+    RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum, h->comm, s));
+  }
+  PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, s));
+  PSBA_HIP(h, hipEventRecord(h->scal_event, s));
   h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   h->backsub_pending = true;
   h->ahead = false;
@@ -607,7 +633,7 @@ int psba_backsub_async(psba_handle h, double mu) {
 }
 
 int psba_linearize_ahead(psba_handle h) {
-  CHECK_H(h);
+  CHECK_H_NOJOIN(h);  // K1 reads and writes nothing the scalar collective touches
   NEED(h, h->backsub_pending || h->backsubbed, "psba_backsub_async / psba_backsub first");
   TRY(launch_linearize(h, false, true));
   h->ahead = true;
@@ -615,9 +641,10 @@ int psba_linearize_ahead(psba_handle h) {
 }
 
 int psba_backsub_wait(psba_handle h, psba_try_scalars *out) {
-  CHECK_H(h);
+  CHECK_H_NOJOIN(h);
   NEED(h, h->backsub_pending, "psba_backsub_async first");
   PSBA_HIP(h, hipEventSynchronize(h->scal_event));
+  h->scal_side = false;  // the host has seen the side stream's work complete
   h->backsub_pending = false;
   // the four sums arrive as SC_NPART partial sets: add them up in a fixed order
   for (int q = 0; q < 4; q++) {
@@ -991,6 +1018,10 @@ int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   RCCL(h, ncclCommInitRank(&h->comm, nranks, id, rank));
+  if (!h->stream2) {
+    PSBA_HIP(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    PSBA_HIP(h, hipEventCreateWithFlags(&h->k3_event, hipEventDisableTiming));
+  }
   h->nranks = nranks;
   h->rank = rank;
   return PSBA_OK;

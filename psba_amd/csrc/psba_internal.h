@@ -124,6 +124,9 @@ struct psba_ctx {
   bool ahead = false;           // the alternate set holds the linearization at the proposed parameters
   bool lin_is_ahead = false;    // the current set was computed ahead: the next psba_linearize is a no-op
   hipEvent_t scal_event = nullptr;  // recorded behind the scalar copy of psba_backsub_async
+  hipStream_t stream2 = nullptr;    // with a communicator: the try's scalar all-reduce + copy run here
+  hipEvent_t k3_event = nullptr;    // K3 done (main stream) -> side stream
+  bool scal_side = false;           // side-stream work the main stream has not been ordered behind yet
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
   int nPart = 0;
   // many cameras (the 27 per-camera accumulators no longer fit a workgroup's LDS): K1 adds its

@@ -234,16 +234,19 @@ def test_venice_sized_parity_away_from_the_initial_point(gpu):
     assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
 
 
-@pytest.mark.parametrize("first_block", ["flush", "expand", "kernel"])
+@pytest.mark.parametrize("first_block", ["flush", "expand", "kernel", "expand+side-stream"])
 def test_single_rank_communicator_runs_the_rccl_path(problems, golden, monkeypatch, first_block):
     """psba_comm_init with one rank: the all-reduce of the packed [tril(S) | ea] sums (then
     scattered into the padded buffer), of the try scalars and of the status flags goes through
-    RCCL on the handle's stream; results must not change.  The first diagonal block of S is
-    factored beside the S-reduce kernel (one rank), beside the scatter kernel after the
-    all-reduce (the route several ranks take), or by a kernel of its own."""
+    RCCL; results must not change.  The first diagonal block of S is factored beside the S-reduce
+    kernel (one rank), beside the scatter kernel after the all-reduce (the route several ranks
+    take), or by a kernel of its own.  side-stream: the scalar all-reduce and its copy on the
+    handle's second stream, beside the linearization queued ahead (what N > 1 does by default)."""
     import psba_amd
-    if first_block == "expand":
+    if first_block.startswith("expand"):
         monkeypatch.setenv("PSBA_SCHUR_NO_FLUSH_DIAG", "1")
+    if first_block.endswith("side-stream"):
+        monkeypatch.setenv("PSBA_COMM_SIDE_STREAM", "1")
     if first_block == "kernel":
         monkeypatch.setenv("PSBA_CHOL_SEPARATE_DIAG", "1")
     h = psba_amd.Psba(0)
