@@ -34,7 +34,7 @@ struct LinArgs {
 // camera-major pass of their own (k_cam_sums) and this kernel leaves them out.
 template <bool DUMP, bool GACC>
 __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
-  __shared__ double sBE[TILE_OBS][8];  // B(6) | e(2) per observation of the tile
+  __shared__ double sBE[TILE_OBS][9];  // B(6) | e(2) per observation of the tile (+1: odd row stride)
   __shared__ double sW[(TILE_OBS / 2) * 19];  // W blocks of half a tile (staged in two halves: LDS for three workgroups per CU)
   extern __shared__ double sAcc[];     // [nC][27]
   const int tid = threadIdx.x;
