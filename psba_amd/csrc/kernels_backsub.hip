@@ -248,8 +248,9 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
   // the fused path's accumulators are zeroed by this try's k_schur_reduce; the sba_func.h mirror
   // may run K3 more than once per assembly, so it zeroes them here
   if (dump) PSBA_HIP(h, hipMemsetAsync(h->scal + SC_PART, 0, 4 * SC_NPART * sizeof(double), h->stream));
-  // persistent workgroups, enough of them per CU to hide the three dependent load phases of a tile
-  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  // persistent workgroups, three per CU (venice-shaped, 1350 tiles, K3 in us by grid: 512 18.7, 640 17.7,
+  // 768 16.6, 896 18.8, 1024 18.2, 1350 17.8)
+  int grid = d.nTiles < 768 ? d.nTiles : 768;
   if (const char *e = getenv("PSBA_BACK_GRID")) grid = atoi(e) > 0 && atoi(e) < grid ? atoi(e) : grid;
   {
     ProfScope ps(h, PSBA_K_BACKSUB);
