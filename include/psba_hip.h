@@ -86,8 +86,8 @@ int psba_reset_params(psba_handle h);
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
 /* which S-assembly route the uploaded problem takes: 0 = LDS-resident partitions of the block
- * triangle with the static schedule (fewer than 2048 cameras, up to 4.19 M observations and 2.1 M
- * points on this rank), 1 = the owner route for larger problems (one thread per block segment,
+ * triangle with the static schedule (fewer than 2048 cameras, up to 8 GB of partial-sum slabs on
+ * this rank), 1 = the owner route for larger problems (one thread per block segment,
  * products sorted by camera pair, sums in registers; PSBA_SCHUR_OWNER=1 forces it), 2 = global
  * fp64 atomics straight into S (the
  * first-generation kernel, kept for cross-checks: PSBA_SCHUR_ATOMIC=1).  The reference has one

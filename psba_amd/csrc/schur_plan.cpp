@@ -76,7 +76,9 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     if (h->nGroups) break;
   }
   h->gblk0.clear();
-  if (h->nGroups && !getenv("PSBA_SCHUR_BLOCK_GROUPS")) {
+  int split = 1;
+  const bool block_ranges = !(h->nGroups && !getenv("PSBA_SCHUR_BLOCK_GROUPS"));
+  if (!block_ranges) {
     for (int g = 0; g <= h->nGroups; g++) h->gblk0.push_back((int)tri(lo[g]));
   } else {
     // more cameras than row-aligned groups hold (a camera row alone outgrows a partition from ~550
@@ -87,9 +89,14 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_blocks = (size_t)atoi(e) * 1024 / sizeof(double) / 37 / ROW * ROW;
     if (budget_blocks > 1008) budget_blocks = 1008;
     const long long G = (total_blocks + (long long)budget_blocks - 1) / (long long)budget_blocks;
-    if (36 * 8 * (double)total_blocks > 1.5e9) return PSBA_OK;  // slabs + reduce traffic beyond what the owner route costs
-    // one workgroup per group walks the whole point sequence: the item fields must hold it
-    if (nObs >= (1 << ITEM_OBS_BITS) || nPts >= (1 << ITEM_PT_BITS)) return PSBA_OK;
+    // a workgroup's stretch of the point sequence must fit the item fields: `split` workgroups (=
+    // slabs) per group at least; the slabs (one copy of tril(S) per split) bound what is worth it
+    split = 1;
+    while ((long long)nObs / split >= (1 << (ITEM_OBS_BITS - 1)) || (long long)nPts / split >= (1 << (ITEM_PT_BITS - 1))) split++;
+    if (const char *e = getenv("PSBA_SCHUR_SPLIT")) split = atoi(e) > split ? atoi(e) : split;  // test hook
+    double slab_max = 8e9;  // full cfg5 (20 M observations): 10 slabs per group, 5.8 GB, K2 9.6 ms against the owner route's 17.6
+    if (const char *e = getenv("PSBA_SCHUR_SLAB_MAX_GB")) slab_max = 1e9 * atof(e);
+    if (36 * 8 * (double)total_blocks * split > slab_max) return PSBA_OK;  // beyond what the owner route costs
     h->nGroups = (int)G;
     for (long long g = 0; g <= G; g++) h->gblk0.push_back((int)(total_blocks * g / G));
   }
@@ -155,11 +162,11 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     const long long cap = total_items / 512;  // small problems: no point in near-empty workgroups
     if (cap < nWg) nWg = (int)(cap < G ? G : cap);
     if (nWg >= 16) nWg -= nWg % 8;
-    if (nWg < G) nWg = G;  // every group needs one
+    if (nWg < G * split) nWg = G * split;  // every group needs `split` of them
   }
-  std::vector<int> gnwg((size_t)G, 1);
+  std::vector<int> gnwg((size_t)G, split);
   {
-    int left = nWg - G;
+    int left = nWg - G * split;
     std::vector<double> want((size_t)G);
     for (int g = 0; g < G; g++) want[g] = total_items ? (double)gitems[g] * nWg / (double)total_items : 1.0;
     while (left > 0) {  // largest remaining deficit first
@@ -212,6 +219,13 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       size_t closed = 0;  // rows [0, closed) are final
       std::vector<uint16_t> mask, mask2;  // bank pairs used once / twice in a row
       std::vector<int> fill;
+      // block ranges (many cameras): a group holds at most one diagonal block, which alone receives
+      // as many items as all its other blocks together (every observation's self-product).  Lanes on
+      // one address are serialised by the LDS whichever rows they sit in, so an item may always
+      // join a row that already has its very position: without this such lists are rows of two
+      // items and fourteen holes (fill 0.54 at cfg5)
+      const bool same_pos_ok = block_ranges;
+      std::vector<std::vector<int>> rowpos;
       auto row_ptr = [&](size_t r) { return out.items.data() + base + r * ROW; };
       for (size_t t = r0; t < r1; t++) {
         const Raw &it = raw[g][t];
@@ -221,7 +235,13 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
                                        ((unsigned long long)it.pos << (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
         const uint16_t bit = (uint16_t)(1u << (it.pos % ROW));
         size_t r = closed;
-        while (r < mask.size() && (fill[r] == ROW || (mask[r] & bit))) r++;
+        auto has_pos = [&](size_t row) {
+          if (!same_pos_ok) return false;
+          for (int q : rowpos[row])
+            if (q == it.pos) return true;
+          return false;
+        };
+        while (r < mask.size() && (fill[r] == ROW || ((mask[r] & bit) && !has_pos(r)))) r++;
         if (r == mask.size() && DUPS && mask.size() - closed >= (size_t)WINDOW) {
           // no clean slot and the window is full: rather than opening a row (and closing the
           // oldest one with holes), let a bank pair be used twice -- one extra LDS pass for
@@ -234,10 +254,12 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
           mask.push_back(0);
           mask2.push_back(0);
           fill.push_back(0);
+          rowpos.emplace_back();
           out.items.resize(base + mask.size() * ROW, SCHUR_NULL_ITEM);
         }
         row_ptr(r)[fill[r]++] = enc;
         mask[r] |= bit;
+        if (same_pos_ok) rowpos[r].push_back(it.pos);
         while (closed < mask.size() && (fill[closed] == ROW || mask.size() - closed > (size_t)WINDOW)) closed++;
       }
       w.item0 = (long long)base;

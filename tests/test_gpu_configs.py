@@ -176,7 +176,7 @@ def test_levmar_on_the_other_bundled_sets(cams, pts, gpu):
 
 @pytest.mark.parametrize("n_cams,k1_global,force_owner",
                          [(250, False, False), (340, False, False), (340, False, True), (455, False, True),
-                          (460, True, False), (700, True, False)])
+                          (460, True, False), (700, True, False), (701, True, False)])
 def test_camera_counts_around_the_k1_limit(gpu, monkeypatch, n_cams, k1_global, force_owner):
     """Up to 455 cameras K1 keeps its 27 per-camera sums in LDS (more than 64 KiB of dynamic LDS
     from ~270 cameras on), beyond that a camera-major pass forms them; K2 splits S into LDS-sized
@@ -189,6 +189,8 @@ def test_camera_counts_around_the_k1_limit(gpu, monkeypatch, n_cams, k1_global, 
     o = Oracle(prob)
     if force_owner:
         monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
+    if n_cams == 701:  # three workgroups (slabs) per block-range group, as problems beyond the item fields get
+        monkeypatch.setenv("PSBA_SCHUR_SPLIT", "3")
     gpu.upload_problem(prob)
     assert gpu.schur_path() == (1 if force_owner else 0)
     lin = o.linearize()
@@ -246,8 +248,8 @@ def test_cfg5_scaled_two_thousand_cameras(gpu, monkeypatch):
     assert np.abs(S - S.T).max() <= 1e-14 * np.abs(S).max()
     rc, dpa = gpu.SPDinv_matVec()
     assert rc == 0
-    # the fused verb, and the owner route (what the full-size cfg5 takes: its 20 M observations are
-    # beyond the item fields of the LDS schedule) through the fused verb
+    # the fused verb, and the owner route (problems beyond 8 GB of slabs or 2047 cameras) through the
+    # fused verb
     gpu.restore_UVdiag()
     for owner in (False, True):
         if owner:
