@@ -126,7 +126,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
 // of the canonical block order for many cameras) whose 6x6 accumulators fit in LDS, and a static schedule built at upload time (schur_plan.cpp) gives every workgroup an
 // equally long list of self-contained 64-bit work items, one per product Y_a W_b^T (b <= a,
 // same point), point-major so that neighbouring lanes read the same W rows:
-//   bits 0..21 a - obs0   22..42 i - pt0   43..53 a - b   54..63 block position in the partition
+//   bits 0..23 a - obs0   24..45 i - pt0   46..53 a - b   54..63 block position in the partition
 // One item per thread: all loads of the product are issued at once, V*^-1 and Y_a are formed
 // in registers and the 6x6 product is added into the LDS partition with ds_add_f64.
 //  * blocks sit at a stride of 37 doubles and the schedule deals items into rows of 16 lanes

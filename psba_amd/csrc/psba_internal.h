@@ -43,10 +43,10 @@ struct Dims {
 };
 
 // one workgroup of k_schur_lds: a range of work items of one group of blocks
-// item = (a - obs0) | (i - pt0) << 22 | (a - b) << 43 | position << 54: observation (22 bits), point
-// (21 bits), distance to the partner observation of the same point (11 bits), block position in the
-// partition (10 bits)
-constexpr int ITEM_OBS_BITS = 22, ITEM_PT_BITS = 21, ITEM_BOFF_BITS = 11, ITEM_POS_BITS = 10;
+// item = (a - obs0) | (i - pt0) << 24 | (a - b) << 46 | position << 54: observation (24 bits), point
+// (22 bits), distance to the partner observation of the same point (8 bits: a point has at most
+// TILE_OBS = 256 observations), block position in the partition (10 bits)
+constexpr int ITEM_OBS_BITS = 24, ITEM_PT_BITS = 22, ITEM_BOFF_BITS = 8, ITEM_POS_BITS = 10;
 struct SchurWg {
   int group, nblk;      // group of blocks; blocks in its LDS partition
   int obs0, pt0;        // the items' observation / point numbers are relative to these

@@ -192,6 +192,10 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   for (int g = 0; g < G; g++) raw[g].reserve((size_t)gitems[g]);
   for (int a = 0; a < nObs; a++) {
     const int ja = jidx[a], i = iidx[a];
+    if (a - ptr[i] >= (1 << ITEM_BOFF_BITS)) {  // (psba_upload_problem refuses such tracks anyway)
+      h->nGroups = 0;
+      return PSBA_OK;
+    }
     for (int b = ptr[i]; b <= a; b++) {
       const size_t blk = (size_t)(tri(ja) + jidx[b]);
       raw[grp_of_blk[blk]].push_back({a, i, a - b, out.blockpos[blk]});

@@ -107,9 +107,9 @@ def _check_plan(nC, nP, iidx, jidx):
         slabs.add((g, slab))
         it = items[s0:s1]
         live = it != np.uint64(0xFFFFFFFFFFFFFFFF)
-        a = obs0 + (it & np.uint64(0x3FFFFF)).astype(np.int64)          # 22 bits
-        i = pt0 + ((it >> np.uint64(22)) & np.uint64(0x1FFFFF)).astype(np.int64)  # 21 bits
-        boff = ((it >> np.uint64(43)) & np.uint64(0x7FF)).astype(np.int64)
+        a = obs0 + (it & np.uint64(0xFFFFFF)).astype(np.int64)          # 24 bits
+        i = pt0 + ((it >> np.uint64(24)) & np.uint64(0x3FFFFF)).astype(np.int64)  # 22 bits
+        boff = ((it >> np.uint64(46)) & np.uint64(0xFF)).astype(np.int64)
         p = ((it >> np.uint64(54)) & np.uint64(0x3FF)).astype(np.int64)
         for r in range(0, len(it), 16):
             q = np.unique(p[r:r + 16][live[r:r + 16]]) % 16  # lanes on one address serialise wherever they sit
