@@ -42,7 +42,7 @@ if cfg5:
         mops, busy = a.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0), a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         frac = busy / (1024 * us * 1e-6 * 2.4e9) if us else 0
         tf = mops * 512 / (us * 1e-6) / 1e12 if us else 0
-        if mops:
+        if mops and "k_cholg" in name:  # (k_schur_reduce's extra workgroup factors the first block: a few MFMAs, not a chain kernel)
             tot_flop += mops * 512 * int(r["Calls"])
             tot_us += us * int(r["Calls"])
         lines.append(f"| `{name}` | {r['Calls']} | {us:.1f} | {float(r['Percentage']):.2f} | {mops:.3g} | {busy:.3g} | "
