@@ -850,7 +850,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 640;
   if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
-  int NB = 256;  // super-panel width of the two-level chain: 64 / 128 / 256 / 512 -> 32.0 / 28.0 / 26.0 / 25.6 ms at n = 12000 (PSBA_CHOL_NB: development knob, multiple of 32)
+  int NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
   if (const char *e = getenv("PSBA_CHOL_NB")) NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : NB;
   // (measured, 6-iteration LM runs: n = 2400 flat 1348 us / two-level 1431; n = 3600 2622 / 2329)
   const bool blocked = !fused && (n32 >= 3072 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
