@@ -25,6 +25,11 @@ while time.time() - t0 < budget:
     lin = o.linearize()
     mu = 1e-3 * lin["maxdiag"]
     sch = o.schur(lin, mu)
+    os.environ.pop("PSBA_SCHUR_SPLIT", None)
+    os.environ.pop("PSBA_SCHUR_BLOCK_GROUPS", None)
+    if rng.random() < 0.3:  # block-range groups (also where row-aligned ones would do), several slabs per group
+        os.environ["PSBA_SCHUR_BLOCK_GROUPS"] = "1"
+        os.environ["PSBA_SCHUR_SPLIT"] = str(int(rng.integers(1, 4)))
     h.upload_problem(prob)
     h.linearize(1.0, 1.0)
     h.schur_assemble(mu)
