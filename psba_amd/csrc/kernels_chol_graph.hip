@@ -852,8 +852,9 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   int NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
   if (const char *e = getenv("PSBA_CHOL_NB")) NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : NB;
-  // (measured, 6-iteration LM runs: n = 2400 flat 1348 us / two-level 1431; n = 3600 2622 / 2329)
-  const bool blocked = !fused && (n32 >= 3072 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
+  // (measured, ms per LM iteration flat / two-level with the fused in-block steps: n = 1542 0.867 /
+  // 0.884, 2040 1.154 / 1.103, 2400 1.385 / 1.287, 2700 1.636 / 1.469)
+  const bool blocked = !fused && (n32 >= 1792 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
   // mid sizes: the fused panel kernel without the identity rows (one kernel per panel instead of
   // trsm + update: the redundant X pieces cost less than the second launch while the panel has few
   // tiles; per solve n = 600: 218 against 267 us, 780: 292 / 356, 1200: 502 / 564, 1542: 763 / 759,
