@@ -88,7 +88,11 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
     size_t budget_blocks = (size_t)159 * 1024 / sizeof(double) / 37 / ROW * ROW;
     if (const char *e = getenv("PSBA_SCHUR_LDS_KB")) budget_blocks = (size_t)atoi(e) * 1024 / sizeof(double) / 37 / ROW * ROW;
     if (budget_blocks > 1008) budget_blocks = 1008;
-    const long long G = (total_blocks + (long long)budget_blocks - 1) / (long long)budget_blocks;
+    long long G = (total_blocks + (long long)budget_blocks - 1) / (long long)budget_blocks;
+    // one workgroup per CU at a time (a partition is most of the LDS): with few rounds, whole rounds
+    // of 256 -- 332 groups at 600 cameras ran as one full round and one of 76 (118 us; as 512 smaller
+    // groups 99; 800 cameras 118 -> 108; from ~900 groups on rounding up costs more than it balances)
+    if (G > 256 && G <= 600 && !getenv("PSBA_SCHUR_NO_ROUNDS")) G = (G + 255) / 256 * 256;
     // a workgroup's stretch of the point sequence must fit the item fields: `split` workgroups (=
     // slabs) per group at least; the slabs (one copy of tril(S) per split) bound what is worth it
     split = 1;
