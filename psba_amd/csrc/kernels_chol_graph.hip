@@ -847,7 +847,9 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   // each, 5x the MFMA work) still fit on the chip's 1024 SIMDs at once; beyond that the
   // redundant work is no longer free: two kernels per panel and a sequential backward solve
   const long long M0 = (nT - 1) - GB / 16;
-  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= 640;
+  long long fused_max = 800;  // i.e. every n32 <= 640, the size k_cholg_solve holds (100 cameras: 0.331 -> 0.295 ms per LM iteration against the mid-size chain)
+  if (const char *e = getenv("PSBA_CHOL_FUSED_MAX")) fused_max = atoll(e);
+  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= fused_max && n32 <= 640;
   if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   int NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
