@@ -183,6 +183,7 @@ int psba_create(int device, psba_handle *out) {
     delete h;
     return rc;
   }
+  if (hipHostGetDevicePointer((void **)&h->h_scal_dev, h->h_scal, 0) != hipSuccess) h->h_scal_dev = nullptr;
   // the status stamps live in the tail of the scalar block so that one copy fetches both
   h->status = reinterpret_cast<int *>(h->scal + 8);
   h->h_status = reinterpret_cast<int *>(h->h_scal + 8);
@@ -624,7 +625,10 @@ int psba_backsub_async(psba_handle h, double mu) {
     }
     RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum, h->comm, s));
   }
-  PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, s));
+  if (h->h_scal_dev && !getenv("PSBA_SCAL_MEMCPY"))
+    TRY(launch_publish_scal(h, s));
+  else
+    PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, s));
   PSBA_HIP(h, hipEventRecord(h->scal_event, s));
   h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   h->backsub_pending = true;

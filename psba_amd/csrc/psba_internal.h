@@ -123,6 +123,7 @@ struct psba_ctx {
   double *W_alt = nullptr, *PV_alt = nullptr, *U_alt = nullptr, *ga_alt = nullptr;
   bool ahead = false;           // the alternate set holds the linearization at the proposed parameters
   bool lin_is_ahead = false;    // the current set was computed ahead: the next psba_linearize is a no-op
+  double *h_scal_dev = nullptr;     // device address of the pinned host block h_scal
   hipEvent_t scal_event = nullptr;  // recorded behind the scalar copy of psba_backsub_async
   hipStream_t stream2 = nullptr;    // with a communicator: the try's scalar all-reduce + copy run here
   hipEvent_t k3_event = nullptr;    // K3 done (main stream) -> side stream
@@ -249,6 +250,7 @@ int launch_chol_solve(psba_ctx *h);
 int launch_chol_graph(psba_ctx *h);
 // kernels_backsub.hip
 int launch_backsub(psba_ctx *h, double mu, bool dump);
+int launch_publish_scal(psba_ctx *h, hipStream_t s);
 // kernels_tr.hip
 int launch_jmul(psba_ctx *h, const double *x1_dev, const double *x2_dev, double *out1_dev, double *dots_dev);
 int launch_pack_g(psba_ctx *h, double *g_dev);
