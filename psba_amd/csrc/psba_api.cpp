@@ -616,8 +616,11 @@ int psba_backsub_async(psba_handle h, double mu) {
     // and the copy instead of behind them (a small all-reduce is ~20-30 us of latency, K1 33 us)
     // (one rank: the collective is a 5 us copy and the two event hops cost more than they hide --
     // 0.221 against 0.213 ms per LM iteration; PSBA_COMM_SIDE_STREAM=1 forces the side stream there,
-    // which is how the tests cover it; N > 1 has not been measured)
-    if (h->stream2 && !getenv("PSBA_COMM_ONE_STREAM") && (h->nranks > 1 || getenv("PSBA_COMM_SIDE_STREAM"))) {
+    // which is how the tests cover it; N > 1 has not been measured
+    // and without a communicator a side stream for the scalar copy alone cost 18 us per iteration
+    // (0.203 against 0.185 ms: the second stream slows the graph launches of the main one), so the
+    // side stream is opt-in until an N > 1 run says otherwise)
+    if (h->stream2 && getenv("PSBA_COMM_SIDE_STREAM")) {
       PSBA_HIP(h, hipEventRecord(h->k3_event, h->stream));
       PSBA_HIP(h, hipStreamWaitEvent(h->stream2, h->k3_event, 0));
       s = h->stream2;

@@ -8,9 +8,9 @@ prob = synth.venice_shaped()
 for rep in range(2):
     for one in (True, False):
         if one:
-            os.environ["PSBA_COMM_ONE_STREAM"] = "1"
+            os.environ.pop("PSBA_COMM_SIDE_STREAM", None)
         else:
-            os.environ.pop("PSBA_COMM_ONE_STREAM", None)
+            os.environ["PSBA_COMM_SIDE_STREAM"] = "1"
         h = psba_amd.Psba(0)
         h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
         h.upload_problem(prob)
