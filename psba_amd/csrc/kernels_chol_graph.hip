@@ -951,10 +951,14 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
 int launch_chol_graph(psba_ctx *h) {
   const int v = h->diag_done ? 1 : 0;
   h->diag_done = false;
-  // large matrices: hundreds of kernels of tens of microseconds each -- a captured graph buys
-  // nothing there (and rocprofv3's kernel tracing has been seen to crash inside the launch of a
-  // graph with ~1200 kernel nodes), so the chain is enqueued directly
-  if (h->n32 > 2048 || getenv("PSBA_CHOL_NO_GRAPH")) {
+  // The chain is enqueued directly.  Replaying it as a captured hipGraph (PSBA_CHOL_GRAPH=1; the
+  // default until late in round 2) is slower at every size on this runtime: per LM iteration with
+  // graph / without, 52 cameras 0.222 / 0.197 ms (the chain itself 84 / 75 us), 100: 0.298 / 0.279,
+  // 257: 0.862 / 0.812, 340: 1.099 / 1.067 -- the host enqueues the 10 ... 150 small kernels faster
+  // than the GPU retires them, and a graph launch costs ~8 us before its first node starts.  (Large
+  // matrices never used one: rocprofv3's kernel tracing has been seen to crash inside the launch of
+  // a graph with ~1200 kernel nodes.)
+  if (h->n32 > 2048 || !getenv("PSBA_CHOL_GRAPH") || getenv("PSBA_CHOL_NO_GRAPH")) {
     ProfScope ps(h, PSBA_K_CHOLESKY);
     enqueue_chain(h, h->stream, v == 1);
     PSBA_HIP(h, hipGetLastError());
