@@ -280,7 +280,12 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   d.maxTrack = maxTrack;
   // K1 keeps 27 accumulators per camera in LDS while they fit beside its tile buffers (nC <= 455);
   // beyond that its camera sums go to global memory with fp64 atomics
-  h->cam_global = (size_t)CAM_ACC * nCams * sizeof(double) > 96 * 1024 || getenv("PSBA_LIN_GLOBAL_ACC");
+  // K1's 27 sums per camera: LDS accumulators per workgroup while they leave room for three
+  // workgroups per CU (up to ~220 cameras: 31 ... 36 us for K1 at 218 k observations), the
+  // camera-major pass beyond (~40 us flat; the LDS form takes 55 us at 257 cameras and 64 at 455,
+  // where it ends: PSBA_LIN_LDS_ACC=1 keeps it up to there)
+  const size_t cam_lds_max = getenv("PSBA_LIN_LDS_ACC") ? 96 * 1024 : 48 * 1024;
+  h->cam_global = (size_t)CAM_ACC * nCams * sizeof(double) > cam_lds_max || getenv("PSBA_LIN_GLOBAL_ACC");
   h->d = d;
   h->nPart = d.nTiles < 768 ? d.nTiles : 768;  // persistent workgroups: three per CU fit since W is staged in halves
   if (const char *e = getenv("PSBA_LIN_GRID")) h->nPart = atoi(e) > 0 && atoi(e) < d.nTiles ? atoi(e) : d.nTiles;

@@ -175,11 +175,12 @@ def test_levmar_on_the_other_bundled_sets(cams, pts, gpu):
 
 
 @pytest.mark.parametrize("n_cams,k1_global,force_owner",
-                         [(250, False, False), (340, False, False), (340, False, True), (455, False, True),
+                         [(250, False, False), (250, True, False), (340, False, False), (340, False, True), (455, False, True),
                           (460, True, False), (700, True, False), (701, True, False)])
 def test_camera_counts_around_the_k1_limit(gpu, monkeypatch, n_cams, k1_global, force_owner):
-    """Up to 455 cameras K1 keeps its 27 per-camera sums in LDS (more than 64 KiB of dynamic LDS
-    from ~270 cameras on), beyond that a camera-major pass forms them; K2 splits S into LDS-sized
+    """K1 can keep its 27 per-camera sums in LDS up to 455 cameras (more than 64 KiB of dynamic LDS
+    from ~270 cameras on; the default up to 227 cameras, forced here with PSBA_LIN_LDS_ACC where
+    k1_global is False), beyond that -- by default from 228 cameras -- a camera-major pass forms them; K2 splits S into LDS-sized
     groups of blocks -- whole camera rows while 128 groups suffice (250 cameras: 56 groups), ranges of
     the canonical block order beyond (460 cameras: 195 groups; from ~550 cameras on a camera row alone
     outgrows a partition) -- or takes the owner route (forced here; psba_schur_path says which).
@@ -189,6 +190,8 @@ def test_camera_counts_around_the_k1_limit(gpu, monkeypatch, n_cams, k1_global, 
     o = Oracle(prob)
     if force_owner:
         monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
+    if not k1_global:
+        monkeypatch.setenv("PSBA_LIN_LDS_ACC", "1")
     if n_cams == 701:  # three workgroups (slabs) per block-range group, as problems beyond the item fields get
         monkeypatch.setenv("PSBA_SCHUR_SPLIT", "3")
     gpu.upload_problem(prob)
