@@ -787,6 +787,7 @@ __global__ __launch_bounds__(256) void k_cholg_back_multi(double *Lw /* the fact
 // diagonal block, R_i the last 32 columns of identity row i in the working buffer and r those of
 // the e_a row, the missing part of the sum is (R_i D^-T)(D^-1 r) = R_i w with
 // w = D^-T D^-1 r -- two 32x32 mat-vecs every workgroup does for itself from LDS.
+template <int NZ>
 __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const double *Lx, int ld, int n, int n32,
                                                     double *x, const double *linv, int *status) {
   __shared__ double sLi[GB][GB + 1], sV[GB], sW[GB];
@@ -799,9 +800,9 @@ __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const dou
   const bool row = i < n;
   const double *y = Lx + (size_t)n32 * ld;
   const double *z = Lx + (size_t)(n32 + 16 + (row ? i : 0)) * ld;
-  double zv[10], yv[10];
+  double zv[NZ], yv[NZ];
 #pragma unroll
-  for (int m = 0; m < 10; m++) {
+  for (int m = 0; m < NZ; m++) {
     const int c = lane + 64 * m;
     const bool on = row && c < jl && c >= (i & ~15);  // left of the diagonal tile: zeros, never written
     zv[m] = on ? z[c] : 0.0;
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const dou
   if (!row) return;
   double acc = lane < GB ? rt * sW[lane] : 0.0;
 #pragma unroll
-  for (int m = 0; m < 10; m++) acc += zv[m] * yv[m];
+  for (int m = 0; m < NZ; m++) acc += zv[m] * yv[m];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) {
@@ -847,9 +848,9 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   // each, 5x the MFMA work) still fit on the chip's 1024 SIMDs at once; beyond that the
   // redundant work is no longer free: two kernels per panel and a sequential backward solve
   const long long M0 = (nT - 1) - GB / 16;
-  long long fused_max = 800;  // i.e. every n32 <= 640, the size k_cholg_solve holds (100 cameras: 0.331 -> 0.295 ms per LM iteration against the mid-size chain)
+  long long fused_max = 2200;  // i.e. every n32 <= 1024, the size k_cholg_solve<16> holds; against the mid-size chain 100 cameras 0.331 -> 0.295 ms per LM iteration, 110: 199 -> 169 us per solve, 130: 244 -> 217, 150: 290 -> 265
   if (const char *e = getenv("PSBA_CHOL_FUSED_MAX")) fused_max = atoll(e);
-  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= fused_max && n32 <= 640;
+  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= fused_max && n32 <= 1024;
   if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   int NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
@@ -920,8 +921,12 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     }
   }
   if (fused) {
-    hipLaunchKernelGGL(k_cholg_solve, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
-                       linv, h->status);
+    if (n32 <= 640)
+      hipLaunchKernelGGL(k_cholg_solve<10>, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
+                         linv, h->status);
+    else
+      hipLaunchKernelGGL(k_cholg_solve<16>, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
+                         linv, h->status);
   } else {
     if (!getenv("PSBA_CHOL_BACK_ONE_WG")) {
       // one small kernel per block, all CUs (see k_cholg_back_panel); against one workgroup walking

@@ -353,11 +353,11 @@ def test_global_atomic_fallback_path(problems, monkeypatch):
     h.close()
 
 
-@pytest.mark.parametrize("n_cams", [96, 106, 200])
+@pytest.mark.parametrize("n_cams", [96, 106, 170, 200])
 def test_many_cameras(gpu, n_cams):
-    """96 and 106 cameras (nA = 576 / 636, n32 = 640: the largest matrix on the fused identity-row
-    chain, 16+ camera-row groups in K2) and 200 (nA = 1200: the fused panel kernel without identity
-    rows + the multi-block backward solve, 50 groups with the whole LDS as budget)."""
+    """96, 106 and 170 cameras (nA = 576 / 636 / 1020; n32 = 1024 is the largest matrix on the fused
+    identity-row chain, k_cholg_solve<10> up to n32 = 640 and <16> beyond) and 200 (nA = 1200: the
+    fused panel kernel without identity rows + the multi-block backward solve)."""
     import psba_amd.synth as synth
     prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=5)
     o = Oracle(prob)
