@@ -268,7 +268,7 @@ def main():
             # by one right after it (ms per LM iteration)
             "ms_per_step_segments": ({"n": len(seg_ms), "median": seg_sorted[len(seg_sorted) // 2],
                                       "min": seg_sorted[0], "max": seg_sorted[-1]} if seg_ms else None),
-            "schur_path": {0: "lds-partitions", 1: "owner (products sorted by camera pair)", 2: "global-atomics"}[h.schur_path()],
+            "schur_path": {0: "lds-partitions", 1: "owner (products sorted by camera pair)", 2: "global-atomics", 3: "ring (owner lanes, LDS-DMA operand ring)"}[h.schur_path()],
             "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
             "roofline": {"kernel": "schur assemble (W/Y/S/ea): k_schur_lds + k_schur_reduce, one HIP-event span over both",
                          "bound": "hbm", "achieved": achieved,

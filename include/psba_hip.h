@@ -184,6 +184,8 @@ typedef struct {
   int verbose;      /* print the reference's per-try line (levmar.cpp:197) */
   int log_cap;      /* rows available in log (5 doubles each), 0 = none */
   int start_itno;   /* the reference shares itno between LM and TR (main.cpp:193-208) */
+  double init_mu;   /* mu_0 = init_mu * max diag(U, V); 0 = the reference's PSBA_INIT_MU 1e-3 (psba.h:6,
+                       levmar.cpp:114-116), a compile-time constant there */
 } psba_lm_options;
 
 typedef struct {
@@ -331,6 +333,32 @@ int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]);
 int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long long *wg,
                          int *blockpos, int *glo);
 void psba_schur_plan_destroy(psba_schur_plan_t p);
+
+/* ---- test hook: the schedule of the S-assembly kernel's ring route (few cameras), host only ----
+ * The lower block triangle of S (reference CL_files/compute_S.cl:6-78) is cut into nR ranges of the
+ * canonical block order and the point sequence into nS stretches; a workgroup per (range, stretch)
+ * replays per-step lists: which runs of W records (up to 7, contiguous in W) are loaded into
+ * which slots of its LDS, which observations get their Y = W V^-1 formed (jobs), and which
+ * product every consumer lane takes.
+ * info[0..15] = nR, nS, workgroups (0: the route does not apply), steps, lane entries, page
+ * loads, jobs, products, lane-steps, lanes per workgroup, LDS slots, records per page load at most, steps between a
+ * load and its first use, lane_blk entries, blk_lane0 entries, record loads.
+ * psba_ring_plan_copy: wg[workgroups][13] = first block, blocks, first row, rows, copy, steps,
+ * the first index of the workgroup in steps / entries / ops / jobs / lane_blk / blk_lane0, and its
+ * W slots (Y slots are numbered from 0 and live behind them);
+ * steps[.][4] = page loads [begin, end) and jobs [begin, end) of the step, relative to the
+ * workgroup; entries[step][lanes] = partner W slot | Y slot << 16 (0xFFFFFFFF: idle);
+ * ops[.][2] = first observation of a page load, first W slot | records << 16;
+ * jobs[.][4] = observation, point, W slot | Y slot << 16, e_a row relative to the first row or -1;
+ * lane_blk[wg][lanes] = block (relative) a lane owns; blk_lane0[.] per workgroup blocks + 1 first
+ * lanes; rb[nR + 1] block range bounds.  Any pointer may be NULL. */
+typedef struct psba_ring_plan *psba_ring_plan_t;
+psba_ring_plan_t psba_ring_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
+                                       const int *jidx);
+int psba_ring_plan_info(psba_ring_plan_t p, long long info[16]);
+int psba_ring_plan_copy(psba_ring_plan_t p, long long *wg, int *steps, unsigned *entries, int *ops,
+                        int *jobs, int *lane_blk, int *blk_lane0, int *rb);
+void psba_ring_plan_destroy(psba_ring_plan_t p);
 
 #ifdef __cplusplus
 }

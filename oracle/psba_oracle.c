@@ -591,7 +591,7 @@ int orc_levmar(int nC, int nP, int nO, const double *K, const double *impts,
     res->t_linearize += now_s() - t0;
 
     if (first) { /* :114-120 */
-      mu = 1e-3 * orc_maxElmOfUV(nT, UVdiag);
+      mu = (opts->init_mu != 0.0 ? opts->init_mu : 1e-3) * orc_maxElmOfUV(nT, UVdiag);
       res->mu0 = mu;
       first = 0;
       p_L2 = 1e+3;

@@ -102,6 +102,7 @@ typedef struct {
   int verbose;
   int log_cap;      /* capacity (rows) of log, 0 = no log */
   int start_itno;   /* itno is a global shared by levmar() and trust_region() (PSBA/main.cpp:193-208) */
+  double init_mu;   /* 0 = PSBA_INIT_MU 1e-3 (PSBA/psba.h:6, levmar.cpp:114-116); a test knob otherwise */
 } orc_lm_opts;
 
 typedef struct {

@@ -32,7 +32,7 @@ class TryScalars(C.Structure):
 
 class LmOptions(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tr_handoff", C.c_int), ("verbose", C.c_int),
-                ("log_cap", C.c_int), ("start_itno", C.c_int)]
+                ("log_cap", C.c_int), ("start_itno", C.c_int), ("init_mu", C.c_double)]
 
 
 class LmResult(C.Structure):
@@ -135,6 +135,10 @@ SIGNATURES = [
     ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
     ("psba_schur_plan_destroy", None, [C.c_void_p]),
+    ("psba_ring_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    ("psba_ring_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    ("psba_ring_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _ip, C.POINTER(C.c_uint), _ip, _ip, _ip, _ip, _ip]),
+    ("psba_ring_plan_destroy", None, [C.c_void_p]),
 ]
 for _name, _res, _args in SIGNATURES:
     _f = getattr(lib, _name)
@@ -235,6 +239,39 @@ def schur_plan(n_cams, n_pts, iidx, jidx):
                 slab_doubles=slab)
 
 
+def ring_plan(n_cams, n_pts, iidx, jidx):
+    """The schedule of the S-assembly kernel's ring route for a sparsity pattern (host only, no
+    device): dict of the arrays psba_ring_plan_copy documents, or None when the route does not
+    apply to the problem."""
+    iidx = _c(iidx, np.int32)
+    jidx = _c(jidx, np.int32)
+    p = lib.psba_ring_plan_create(int(n_cams), int(n_pts), int(iidx.size), _i(iidx), _i(jidx))
+    if not p:
+        raise PsbaError(-1, "psba_ring_plan_create failed")
+    try:
+        info = (C.c_longlong * 16)()
+        lib.psba_ring_plan_info(p, info)
+        (nR, nS, nwg, nsteps, nent, nops, njob, products, slots, lanes, pages, yslots, lat, nlb, nbl0, loaded) = (int(x) for x in info)
+        if nwg == 0:
+            return None
+        wg = np.zeros((nwg, 13), dtype=np.int64)
+        steps = np.zeros((nsteps, 4), dtype=np.int32)
+        entries = np.zeros(nent, dtype=np.uint32)
+        ops = np.zeros((nops, 2), dtype=np.int32)
+        jobs = np.zeros((njob, 4), dtype=np.int32)
+        lane_blk = np.zeros(nlb, dtype=np.int32)
+        blk_lane0 = np.zeros(nbl0, dtype=np.int32)
+        rb = np.zeros(nR + 1, dtype=np.int32)
+        lib.psba_ring_plan_copy(p, wg.ctypes.data_as(C.POINTER(C.c_longlong)), _i(steps),
+                                entries.ctypes.data_as(C.POINTER(C.c_uint)), _i(ops), _i(jobs), _i(lane_blk),
+                                _i(blk_lane0), _i(rb))
+    finally:
+        lib.psba_ring_plan_destroy(p)
+    return dict(nR=nR, nS=nS, wg=wg, steps=steps, entries=entries, ops=ops, jobs=jobs, lane_blk=lane_blk,
+                blk_lane0=blk_lane0, rb=rb, products=products, lane_steps=slots, lanes=lanes, slots=pages,
+                page=yslots, lat=lat, loaded_recs=loaded)
+
+
 def shard_problem(prob, nranks, rank):
     """The sub-problem rank `rank` owns: a contiguous point range and its observations;
     cameras are replicated."""
@@ -298,7 +335,8 @@ class Psba:
 
     # ---- fused verbs ----
     def schur_path(self):
-        """0: LDS-partition schedule, 1: global-atomic assembly kernel (psba_schur_path)."""
+        """0: LDS-partition schedule, 1: owner route, 2: global-atomic assembly kernel, 3: ring route
+        (psba_schur_path)."""
         v = C.c_int()
         self._ck(lib.psba_schur_path(self._h, C.byref(v)))
         return v.value
@@ -417,8 +455,8 @@ class Psba:
         return self._out(lib.psba_update_p, self.nT)[1]
 
     # ---- LM ----
-    def levmar(self, max_iter=50, tr_handoff=False, verbose=False, log_cap=512, start_itno=0):
-        opts = LmOptions(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno)
+    def levmar(self, max_iter=50, tr_handoff=False, verbose=False, log_cap=512, start_itno=0, init_mu=0.0):
+        opts = LmOptions(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno, init_mu)
         res = LmResult()
         log = np.zeros((max(log_cap, 1), 5))
         self._ck(lib.psba_levmar(self._h, C.byref(opts), C.byref(res), _d(log)))

@@ -18,13 +18,14 @@ void psba_lm_default_options(psba_lm_options *o) {
   o->verbose = 0;
   o->log_cap = 0;
   o->start_itno = 0;
+  o->init_mu = 0.0;
 }
 
 int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res, double *log) {
   if (!h || !opts || !res) return PSBA_E_INVALID;
   const double STOP = 1e-12;           // PSBA_STOP_THRESH, psba.h:7
   const double EPS_SQ = 1e-12 * 1e-12; // PSBA_EPSILON_SQ, psba.h:10
-  const double tau = 1e-3;             // PSBA_INIT_MU, psba.h:6
+  const double tau = opts->init_mu != 0.0 ? opts->init_mu : 1e-3;  // PSBA_INIT_MU, psba.h:6
   *res = psba_lm_result();
   auto t_begin = std::chrono::steady_clock::now();
   int rc;

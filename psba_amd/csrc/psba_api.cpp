@@ -137,6 +137,16 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->diag0);
   dev_free(h->redp);
   dev_free(h->slab);
+  dev_free(h->ring_wg);
+  dev_free(h->ring_steps);
+  dev_free(h->ring_entries);
+  dev_free(h->ring_ops);
+  dev_free(h->ring_jobs);
+  dev_free(h->ring_bl0);
+  dev_free(h->ring_canon);
+  dev_free(h->ring_slab);
+  dev_free(h->ring_pvi);
+  h->ring_nWg = h->ring_nS = 0;
   dev_free(h->own_prod);
   dev_free(h->own_waves);
   dev_free(h->own_units);
@@ -216,7 +226,7 @@ int psba_destroy(psba_handle h) {
 int psba_schur_path(psba_handle h, int *path) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  if (path) *path = getenv("PSBA_SCHUR_ATOMIC") ? 2 : h->nGroups > 0 ? 0 : 1;
+  if (path) *path = getenv("PSBA_SCHUR_ATOMIC") ? 2 : h->ring_nWg > 0 ? 3 : h->nGroups > 0 ? 0 : 1;
   return PSBA_OK;
 }
 
@@ -351,6 +361,48 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
   // ---- K2's static schedule (groups of blocks, workgroups, conflict-free item rows) ----
   {
+    RingPlanHost rp;
+    TRY(build_ring_plan(nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), rp));
+    if (rp.nWg > 0) {
+      h->packedN = 36 * (size_t)nCams * (nCams + 1) / 2;
+      h->nGroups = 0;
+      h->ring_nWg = rp.nWg;
+      h->ring_nS = rp.nS;
+      h->ring_products = rp.products;
+      h->ring_slots = rp.slots;
+      h->ring_loaded_recs = (size_t)rp.loaded_recs;
+      std::vector<int> canon;
+      for (int j = 0; j < nCams; j++)
+        for (int k = 0; k <= j; k++) canon.push_back((j << 16) | k);
+      auto up = [&](auto **dst, const auto &v) -> int {
+        TRY(dev_alloc(h, dst, v.size() ? v.size() : 1));
+        if (v.size()) PSBA_HIP(h, hipMemcpy(*dst, v.data(), sizeof(v[0]) * v.size(), hipMemcpyHostToDevice));
+        return PSBA_OK;
+      };
+      TRY(up(&h->ring_wg, rp.wgs));
+      TRY(up(&h->ring_steps, rp.steps));
+      TRY(up(&h->ring_entries, rp.entries));
+      TRY(up(&h->ring_ops, rp.ops));
+      TRY(up(&h->ring_jobs, rp.jobs));
+      TRY(up(&h->ring_bl0, rp.blk_lane0));
+      TRY(up(&h->ring_canon, canon));
+      TRY(dev_alloc(h, &h->ring_slab, (size_t)rp.nS * h->packedN));
+      TRY(dev_alloc(h, &h->ring_pvi, (size_t)9 * n3Dpts + 2));
+      h->packed_doubles = h->packedN;
+      TRY(dev_alloc(h, &h->redp, h->packed_doubles));
+      if (getenv("PSBA_SCHUR_PLAN_INFO")) {
+        long long steps_max = 0;
+        for (const auto &w : rp.wgs) steps_max = w.nsteps > steps_max ? w.nsteps : steps_max;
+        fprintf(stderr, "[psba] K2 ring route: %d block ranges x %d stretches, %lld products in %lld lane-steps (fill %.3f), "
+                        "%lld record loads (%.2f per observation), %zu jobs, steps <= %lld, lists %.1f MB, copies %.1f MB\n",
+                rp.nR, rp.nS, rp.products, rp.slots, rp.slots ? (double)rp.products / (double)rp.slots : 1.0,
+                rp.loaded_recs, (double)rp.loaded_recs / n2Dprojs, rp.jobs.size(), steps_max,
+                1e-6 * (4.0 * rp.entries.size() + 4.0 * rp.ops.size() + 16.0 * rp.jobs.size() + 16.0 * rp.steps.size()),
+                8e-6 * (double)rp.nS * (double)h->packedN);
+      }
+    }
+  }
+  if (!h->ring_nWg) {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
     if (h->nGroups) {
@@ -697,8 +749,10 @@ int psba_accept(psba_handle h) {
     std::swap(h->PV, h->PV_alt);
     std::swap(h->U, h->U_alt);
     std::swap(h->ga, h->ga_alt);
-    h->lin_is_ahead = true;
   }
+  // only a linearization that was computed ahead for THIS proposal spares the next psba_linearize
+  // (an earlier accept's flag must not survive: psba_set_step -> psba_accept -> psba_linearize)
+  h->lin_is_ahead = h->ahead;
   h->ahead = false;
   return PSBA_OK;
 }
@@ -774,6 +828,9 @@ int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *i
     // Cholesky on a copy of it (trust_region.cpp:341-363)
     NEED(h, h->linearized, "psba_linearize first");
     TRY(launch_schur(h, 0.0, false));
+    // with a communicator (even of one rank) the sums sit in the packed buffer until the all-reduce
+    // and k_schur_expand have run: the modified Cholesky must not factor a stale square
+    if (h->packed_pending) TRY(allreduce_schur(h));
   }
   h->diag_done = false;  // the first diagonal block's factor in chol_L is about to be overwritten
   TRY(launch_cholmod(h, h->scal + SC_CHOLMOD));
@@ -1054,7 +1111,9 @@ int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
 
 // (with the PSBA_SCHUR_PACKED test hook the buffer is the packed [tril(S) | e_a] sums a
 // communicator would all-reduce: 36 doubles per block of the lower block triangle)
-static bool packed_hook(psba_ctx *h) { return !h->comm && h->nranks > 1 && h->nGroups > 0 && getenv("PSBA_SCHUR_PACKED"); }
+static bool packed_hook(psba_ctx *h) {
+  return !h->comm && h->nranks > 1 && (h->nGroups > 0 || h->ring_nWg > 0) && getenv("PSBA_SCHUR_PACKED");
+}
 
 int psba_reduce_buffer_size(psba_handle h, long long *n_doubles) {
   CHECK_H(h);
@@ -1234,5 +1293,82 @@ int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long lo
 }
 
 void psba_schur_plan_destroy(psba_schur_plan_t p) { delete p; }
+
+// ---- test hook: the ring route's schedule (schur_ring_plan.cpp), host only ----
+struct psba_ring_plan {
+  psba::RingPlanHost plan;
+};
+
+psba_ring_plan_t psba_ring_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, const int *jidx) {
+  if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !iidx || !jidx) return nullptr;
+  std::vector<int> ptr((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return nullptr;
+    if (a && (iidx[a] < iidx[a - 1] || (iidx[a] == iidx[a - 1] && jidx[a] <= jidx[a - 1]))) return nullptr;
+    ptr[(size_t)iidx[a] + 1]++;
+  }
+  for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[i];
+  psba_ring_plan *p = new (std::nothrow) psba_ring_plan;
+  if (!p) return nullptr;
+  if (psba::build_ring_plan(nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), p->plan, true) != PSBA_OK) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+int psba_ring_plan_info(psba_ring_plan_t p, long long info[16]) {
+  if (!p || !info) return PSBA_E_INVALID;
+  const psba::RingPlanHost &q = p->plan;
+  info[0] = q.nR;
+  info[1] = q.nS;
+  info[2] = q.nWg;
+  info[3] = (long long)q.steps.size();
+  info[4] = (long long)q.entries.size();
+  info[5] = (long long)q.ops.size() / 2;
+  info[6] = (long long)q.jobs.size();  // (each list ends in a few entries of slack the kernel may read but never uses)
+  info[7] = q.products;
+  info[8] = q.slots;
+  info[9] = psba::RING_LANES;
+  info[10] = psba::RING_SLOTS;
+  info[11] = psba::RING_PAGE;
+  info[12] = q.lat;
+  info[13] = (long long)q.lane_blk.size();
+  info[14] = (long long)q.blk_lane0.size();
+  info[15] = q.loaded_recs;
+  return PSBA_OK;
+}
+
+int psba_ring_plan_copy(psba_ring_plan_t p, long long *wg, int *steps, unsigned *entries, int *ops, int *jobs,
+                        int *lane_blk, int *blk_lane0, int *rb) {
+  if (!p) return PSBA_E_INVALID;
+  const psba::RingPlanHost &q = p->plan;
+  if (wg)
+    for (size_t k = 0; k < q.wgs.size(); k++) {
+      const psba::RingWg &w = q.wgs[k];
+      long long *o = wg + 13 * k;
+      o[12] = w.nwslots;
+      o[0] = w.blk0; o[1] = w.nblk; o[2] = w.row0; o[3] = w.nrows; o[4] = w.copy; o[5] = w.nsteps;
+      o[6] = w.step0; o[7] = w.ent0; o[8] = w.op0; o[9] = w.job0; o[10] = w.lane0; o[11] = w.bl0;
+    }
+  if (steps)
+    for (size_t k = 0; k < q.steps.size(); k++) {
+      steps[4 * k] = q.steps[k].op_begin; steps[4 * k + 1] = q.steps[k].op_end;
+      steps[4 * k + 2] = q.steps[k].job_begin; steps[4 * k + 3] = q.steps[k].job_end;
+    }
+  if (entries) std::copy(q.entries.begin(), q.entries.end(), entries);
+  if (ops) std::copy(q.ops.begin(), q.ops.end(), ops);
+  if (jobs)
+    for (size_t k = 0; k < q.jobs.size(); k++) {
+      jobs[4 * k] = q.jobs[k].obs; jobs[4 * k + 1] = q.jobs[k].point;
+      jobs[4 * k + 2] = q.jobs[k].slots; jobs[4 * k + 3] = q.jobs[k].earow;
+    }
+  if (lane_blk) std::copy(q.lane_blk.begin(), q.lane_blk.end(), lane_blk);
+  if (blk_lane0) std::copy(q.blk_lane0.begin(), q.blk_lane0.end(), blk_lane0);
+  if (rb) std::copy(q.rb.begin(), q.rb.end(), rb);
+  return PSBA_OK;
+}
+
+void psba_ring_plan_destroy(psba_ring_plan_t p) { delete p; }
 
 }  // extern "C"

@@ -83,6 +83,40 @@ struct OwnerPlanHost {
   std::vector<OwnerUnit> units;    // 64 per wave
   long long products = 0;
 };
+// ---- K2 ring route (few cameras): schur_ring_plan.cpp / kernels_schur_ring.hip ----
+constexpr int RING_LANES = 256;      // consumer lanes of a workgroup (4 waves); every lane owns one 6x6 block
+constexpr int RING_MOVERS = 4;       // waves that stream W records into the LDS ring with LDS-DMA
+constexpr int RING_PREPPERS = 4;     // waves that form Y_a = W_a V*^-1 (two lanes per job)
+constexpr int RING_PREP_JOBS = 32;   // jobs per prepper wave and step
+constexpr int RING_PAGE = 7;         // W records per page load at most: one LDS-DMA instruction moves up to 63 x 16 B, contiguous in W and in LDS
+constexpr int RING_SLOTS = 992;      // 144-byte LDS slots in all: W records first, Y behind them
+constexpr int RING_MAXOPS = 16;      // page loads per mover wave and step at most
+constexpr unsigned RING_NULL_ENTRY = 0xFFFFFFFFu;
+struct RingStep { int op_begin, op_end, job_begin, job_end; };  // the page loads and jobs of a step (relative to the workgroup's lists)
+struct RingJob {
+  int obs, point;   // the a-side observation and its point
+  int slots;        // slot of W_a | Y slot << 16
+  int earow;        // row (relative to the workgroup's first) whose e_a this job feeds, -1: not here
+};
+struct RingWg {
+  int blk0, nblk;   // blocks [blk0, blk0 + nblk) of the canonical order tri(j) + k
+  int row0, nrows;  // camera rows those blocks lie in
+  int copy, nsteps; // which copy of the packed triangle the sums go to; steps (even)
+  int nwslots, pad; // W slots of this workgroup's LDS; the Y slots follow them
+  long long step0, ent0, op0, job0, lane0, bl0;  // first entry of this workgroup in the plan's lists
+};
+struct RingPlanHost {
+  int nR = 0, nS = 0, nWg = 0, lat = 2;
+  std::vector<int> rb;              // block range r = [rb[r], rb[r+1])
+  std::vector<RingWg> wgs;          // range-major: index r * nS + s
+  std::vector<RingStep> steps;
+  std::vector<unsigned> entries;    // [step][RING_LANES]: partner slot | Y slot << 16, or RING_NULL_ENTRY
+  std::vector<int> ops;             // [op][2]: first observation of the run of records, first slot | records << 16
+  std::vector<RingJob> jobs;
+  std::vector<int> lane_blk;        // [wg][RING_LANES] lane -> local block (-1: idle)
+  std::vector<int> blk_lane0;       // [wg][nblk + 1] first lane of each local block
+  long long products = 0, slots = 0, loaded_recs = 0;
+};
 struct SchurPlanHost {
   std::vector<unsigned long long> items;
   std::vector<SchurWg> wgs;
@@ -166,6 +200,21 @@ struct psba_ctx {
   int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
+  // K2 ring route (few cameras): see RingPlanHost
+  int ring_nWg = 0, ring_nS = 0;
+  psba::RingWg *ring_wg = nullptr;
+  psba::RingStep *ring_steps = nullptr;
+  unsigned *ring_entries = nullptr;
+  int *ring_ops = nullptr;
+  psba::RingJob *ring_jobs = nullptr;
+  int *ring_bl0 = nullptr;
+  int *ring_canon = nullptr;    // [tri(nC)] (j << 16) | k of every block of the canonical order
+  double *ring_slab = nullptr;  // [ring_nS][packedN] copies of the packed triangle
+  double *ring_pvi = nullptr;   // [nP][9] (V_i + mu I)^-1 (sym6) | (V_i + mu I)^-1 g_b,i of the current try (k_schur_vinv)
+  long long ring_products = 0, ring_slots = 0;
+  size_t ring_loaded_recs = 0;
+  bool ring_attr_set = false;
+  long long *chol_tim_ring = nullptr;  // dev instrumentation (PSBA_RING_TIMING): per-step s_memtime stamps of two workgroups
   // K2 owner route (many cameras): see OwnerPlanHost
   int2 *own_prod = nullptr;
   psba::OwnerWave *own_waves = nullptr;
@@ -242,6 +291,9 @@ int launch_max_diag(psba_ctx *h);
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
                      const int *ptr, SchurPlanHost &out);
 int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out);
+int build_ring_plan(int nCams, int nPts, int nObs, const int *iidx, const int *jidx, const int *ptr, RingPlanHost &out,
+                    bool force = false);
+int launch_schur_ring(psba_ctx *h, double mu, bool dump);
 int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip

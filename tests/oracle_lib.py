@@ -13,7 +13,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 class LmOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tr_handoff", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int),
-                ("start_itno", C.c_int)]
+                ("start_itno", C.c_int), ("init_mu", C.c_double)]
 
 
 class LmResult(C.Structure):
@@ -128,8 +128,8 @@ class Oracle:
         _dpb(self.nC, self.nP, sch["Vinv"], eab, dp)
         return ret, dp, eab
 
-    def levmar(self, max_iter=50, tr_handoff=False, log_cap=512, verbose=False, start_itno=0):
-        opts = LmOpts(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno)
+    def levmar(self, max_iter=50, tr_handoff=False, log_cap=512, verbose=False, start_itno=0, init_mu=0.0):
+        opts = LmOpts(max_iter, int(tr_handoff), int(verbose), log_cap, start_itno, init_mu)
         res = LmResult()
         log = np.zeros((max(log_cap, 1), 5))
         _lm(self.nC, self.nP, self.nO, self.K, self.impts, self.initrot, self.cams, self.pts, self.iidx,
@@ -216,7 +216,7 @@ def levmar_all_cores(prob, max_iter=10, tr_handoff=False):
     f.argtypes = _lm.argtypes
     lib.orc_threads.restype = C.c_int
     o = Oracle(prob)
-    opts = LmOpts(max_iter, int(tr_handoff), 0, 0, 0)
+    opts = LmOpts(max_iter, int(tr_handoff), 0, 0, 0, 0.0)
     res = LmResult()
     log = np.zeros((1, 5))
     f(o.nC, o.nP, o.nO, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, C.byref(opts), C.byref(res),

@@ -277,6 +277,114 @@ def test_cfg5_scaled_two_thousand_cameras(gpu, monkeypatch):
     assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
 
 
+def test_cfg5_full_size(monkeypatch):
+    """BASELINE configs[4] at FULL size (synth.cfg5(): 2000 cameras x 2 M points x 20 M observations,
+    dense 12 000 x 12 000 S).  The oracle cannot follow at this size, so the checks are properties:
+    the problem takes the LDS-partition route with several workgroups per group of blocks by itself
+    (its observation range does not fit one workgroup's item fields), S is symmetric, S and e_a agree
+    between that route and the forced owner route to 1e-11, ||S dpa - e_a|| is at rounding level, and
+    three LM iterations decrease the cost."""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.cfg5()
+    assert (prob["nC"], prob["nP"], prob["nO"]) == (2000, 2_000_000, 20_000_000)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 0
+    h.linearize(1.0, 1.0)
+    mu = 1e-3 * h.max_diag()
+    nA = 6 * 2000
+    h.schur_assemble(mu)
+    M = h.get_reduce_buffer().reshape(nA + 1, nA)  # 12000 is a multiple of 32: no padding
+    S, ea = M[:nA].copy(), M[nA].copy()
+    del M
+    scale = np.abs(S).max()
+    assert np.abs(S - S.T).max() <= 1e-14 * scale
+    h.schur_reduce()
+    h.schur_solve()
+    sc = h.backsub(mu)
+    assert sc.status == 0
+    dpa = h.get_dp()[:nA]
+    r = S @ dpa - ea
+    bound = np.abs(S).sum(axis=1).max() * np.abs(dpa).max() + np.abs(ea).max()  # inf-norms
+    assert np.abs(r).max() <= 1e-11 * bound, np.abs(r).max() / bound
+    res, log = h.levmar(max_iter=3, tr_handoff=False)
+    acc = log[log[:, 4] > 0]
+    assert len(acc) >= 2 and np.all(np.diff(np.r_[res.init_err, acc[:, 1]]) < 0)
+    h.close()
+    monkeypatch.setenv("PSBA_SCHUR_OWNER", "1")
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 1
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    M = h.get_reduce_buffer().reshape(nA + 1, nA)
+    assert np.abs(M[:nA] - S).max() <= 1e-11 * scale
+    assert np.abs(M[nA] - ea).max() <= 1e-10 * np.abs(ea).max()
+    h.close()
+
+
+def test_owner_route_beyond_the_lds_limit_of_the_atomic_kernel():
+    """More than 2133 cameras: 8 nA exceeds the 100 KiB of LDS the first-generation global-atomic
+    kernel keeps e_a in; the owner route needs no such table and must not be refused for it (ADVICE
+    r2).  S / e_a through the fused verb against sums formed in numpy from the oracle's W, V, U, g."""
+    import psba_amd
+    import psba_amd.synth as synth
+    nC = 2200
+    prob = synth.make_problem(n_cams=nC, n_pts=1500, mean_track=4.0, seed=2200)
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 1
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    nA = 6 * nC
+    n32 = (nA + 31) // 32 * 32
+    M = h.get_reduce_buffer().reshape(n32 + 1, n32)
+    iidx, jidx = np.asarray(prob["iidx"]), np.asarray(prob["jidx"])
+    W = lin["W"].reshape(-1, 6, 3)
+    V = lin["V"].reshape(-1, 3, 3) + mu * np.eye(3)
+    Y = np.einsum("ors,ost->ort", W, np.linalg.inv(V)[iidx])
+    S = np.zeros((nA, nA))
+    U = lin["U"].reshape(nC, 6, 6)
+    for j in range(nC):
+        S[6 * j: 6 * j + 6, 6 * j: 6 * j + 6] = U[j] + mu * np.eye(6)
+    ptr = np.searchsorted(iidx, np.arange(prob["nP"] + 1))
+    for i in range(prob["nP"]):
+        for a in range(ptr[i], ptr[i + 1]):
+            for b in range(ptr[i], ptr[i + 1]):
+                S[6 * jidx[a]: 6 * jidx[a] + 6, 6 * jidx[b]: 6 * jidx[b] + 6] -= Y[a] @ W[b].T
+    g = lin["g"]
+    ea = g[:nA].copy()
+    np.subtract.at(ea.reshape(nC, 6), jidx, np.einsum("ort,ot->or", Y, g[nA:].reshape(-1, 3)[iidx]))
+    close(M[:nA, :nA], S, 1e-11, "S (owner route, 2200 cameras)")
+    close(M[n32, :nA], ea, 1e-10, "ea")
+    h.close()
+
+
+def test_levmar_through_failed_first_tries(problems):
+    """psba_levmar driven through PSBA_NOT_SPD tries (reference PSBA/levmar.cpp:227-244: mu *= nu,
+    nu *= 2, no step): with mu_0 = 1e-30 max diag the first Schur complements are singular to
+    rounding (no gauge is fixed), their factorizations fail, the log carries -1 rows, and once mu
+    has grown the run must end where the oracle's does."""
+    import psba_amd
+    prob = problems["7cams"]
+    ores, olog = Oracle(prob).levmar(max_iter=50, tr_handoff=False, init_mu=1e-30)
+    assert (olog[:, 4] < 0).sum() >= 1 and olog[0, 4] == -1
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    res, log = h.levmar(max_iter=50, tr_handoff=False, init_mu=1e-30)
+    h.close()
+    assert log[0, 4] == -1 and np.isnan(log[0, 1]) and log[0, 3] == olog[0, 3]
+    fails = log[log[:, 4] < 0]
+    assert len(fails) >= 1 and np.all(np.diff(fails[:, 3]) > 0)  # every failed try raises mu
+    # which of the borderline tries fail depends on rounding; where the run ends does not
+    assert res.flag == ores.flag
+    assert abs(res.final_err - ores.final_err) <= 1e-9 * ores.final_err
+
+
 @pytest.mark.parametrize("one_wg", [False, True])
 def test_backward_solve_variants(monkeypatch, one_wg):
     """The backward solve of the unfused chains: one kernel per 32-column block over all CUs
@@ -284,6 +392,7 @@ def test_backward_solve_variants(monkeypatch, one_wg):
     PSBA_CHOL_BACK_ONE_WG=1, kept for comparison), at a size the oracle solves quickly."""
     import psba_amd
     import psba_amd.synth as synth
+    monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")  # (130 cameras would take the fused identity-row chain, which has no backward kernel)
     if one_wg:
         monkeypatch.setenv("PSBA_CHOL_BACK_ONE_WG", "1")
     prob = synth.make_problem(n_cams=130, n_pts=3000, mean_track=5.0, seed=77)
@@ -312,6 +421,7 @@ def test_two_level_blocked_panel_chain(monkeypatch, n_cams):
     import psba_amd
     import psba_amd.synth as synth
     monkeypatch.setenv("PSBA_CHOL_BLOCKED", "1")
+    monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")  # (the two-level chain is a form of the unfused one: blocked = !fused && ...)
     prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=300 + n_cams)
     o = Oracle(prob)
     lin = o.linearize()
@@ -358,6 +468,50 @@ def test_single_rank_communicator_with_many_cameras(problems, monkeypatch, force
     h.close()
 
 
+@pytest.mark.parametrize("name", ["7cams", "54cams", "trafalgar21"])
+def test_ring_route_opt_in(name, problems, monkeypatch):
+    """K2's ring route (PSBA_SCHUR_RING=1: blocks of S owned by lanes, W records streamed into LDS by
+    LDS-DMA following a host-simulated schedule; built in round 3, measured slower than the
+    LDS-partition route and therefore opt-in) must stay correct: the mirror verbs' Vinv / Y
+    / S / ea against the oracle, the fused verb's reduce buffer, and a short LM run against the
+    default route."""
+    import psba_amd
+    prob = problems[name]
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    ref = psba_amd.Psba(0)
+    ref.upload_problem(prob)
+    assert ref.schur_path() == 0
+    want, _ = ref.levmar(max_iter=6, tr_handoff=False)
+    ref.close()
+    monkeypatch.setenv("PSBA_SCHUR_RING", "1")
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 3
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    rc, Vinv = h.compute_Vinv()
+    assert rc == 0
+    close(Vinv, sch["Vinv"], 1e-10, "Vinv")
+    close(h.compute_Yblks(), sch["Y"], 1e-10, "Y")
+    S = h.compute_S()
+    close(S, sch["S"], 1e-11, "S")
+    close(h.compute_ea(), sch["eab"][: o.nA], 1e-10, "ea")
+    h.restore_UVdiag()
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    n32 = (o.nA + 31) // 32 * 32
+    M = h.get_reduce_buffer().reshape(n32 + 1, n32)
+    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S (fused verb)")
+    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea (fused verb)")
+    h.upload_problem(prob)
+    res, _ = h.levmar(max_iter=6, tr_handoff=False)
+    assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-10 * want.final_err
+    h.close()
+
+
 @pytest.mark.parametrize("name,nr", [("54cams", 2), ("trafalgar21", 3)])
 def test_packed_sums_line_up_between_ranks(name, nr, problems, monkeypatch):
     """What RCCL all-reduces with a communicator is the packed [tril(S) | e_a] buffer.  Every rank
@@ -380,7 +534,7 @@ def test_packed_sums_line_up_between_ranks(name, nr, problems, monkeypatch):
         h = psba_amd.Psba(0)
         h.set_rank_layout(nr, r)
         h.upload_problem(capi.shard_problem(prob, nr, r))
-        assert h.schur_path() == 0
+        assert h.schur_path() in (0, 3)  # LDS partitions or the ring route: both pack canonically
         h.linearize(1.0, 1.0)
         h.schur_assemble(mu)
         hs.append(h)

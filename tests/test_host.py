@@ -161,6 +161,87 @@ def test_schur_plan_many_cameras(n_cams):
     assert np.diff(glo).max() * 37 * 8 <= 160 * 1024 - 256
 
 
+def _replay_ring_plan(nC, nP, iidx, jidx, max_wgs=None):
+    """Replays the ring route's schedule (schur_ring_plan.cpp) the way k_schur_ring does and checks
+    what the kernel relies on: a lane only ever gets products of the block it owns; both operands
+    of a product are in the slots its entry names -- the partner's W record loaded at least `lat`
+    steps earlier and not overwritten since, Y_a prepared (one step after its W_a was loaded) and
+    still there; every product (a, b <= a, same point) is taken exactly once by the workgroup of
+    its block range and point stretch; every observation feeds e_a exactly once."""
+    from psba_amd import capi
+    plan = capi.ring_plan(nC, nP, iidx, jidx)
+    assert plan is not None
+    wg, steps, ent, ops, jobs = plan["wg"], plan["steps"], plan["entries"], plan["ops"], plan["jobs"]
+    lanes, lat, page, nslots = plan["lanes"], plan["lat"], plan["page"], plan["slots"]
+    ptr = np.searchsorted(iidx, np.arange(nP + 1))
+    rb = plan["rb"]
+    assert rb[0] == 0 and rb[-1] == nC * (nC + 1) // 2 and (np.diff(rb) > 0).all()
+    seen, ea_seen = set(), set()
+    full = max_wgs is None
+    pick = range(len(wg)) if full else np.linspace(0, len(wg) - 1, max_wgs).astype(int)
+    for w in pick:
+        blk0, nblk, row0, nrows, copy, nsteps, step0, ent0, op0, job0, lane0, bl0, nw = (int(x) for x in wg[w])
+        assert nsteps % 4 == 0 and 0 < nw < nslots and 0 <= copy < plan["nS"]
+        lane_blk = plan["lane_blk"][lane0:lane0 + lanes]
+        first = plan["blk_lane0"][bl0:bl0 + nblk + 1]
+        assert first[0] == 0 and first[-1] <= lanes and (np.diff(first) >= 1).all()
+        for b in range(nblk):
+            assert (lane_blk[first[b]:first[b + 1]] == b).all()
+        wslot = {}   # slot -> (observation, step of its load)
+        yslot = {}   # Y slot -> (observation, step in which it is written)
+        for t in range(nsteps):
+            ob, oe, jb, je = (int(x) for x in steps[step0 + t])
+            assert oe - ob <= 4 * 16 and je - jb <= 4 * 32
+            for a0, sn in ops[op0 + ob: op0 + oe]:
+                s0, n = int(sn) & 0xFFFF, int(sn) >> 16
+                assert 1 <= n <= page and s0 + n <= nw
+                assert iidx[a0] == iidx[a0 + n - 1]  # a run of records of one point: contiguous in W
+                for r in range(n):
+                    wslot[s0 + r] = (int(a0) + r, t)
+            e = ent[ent0 + t * lanes: ent0 + (t + 1) * lanes]
+            for l in np.nonzero(e != 0xFFFFFFFF)[0]:
+                ws, ys = int(e[l]) & 0xFFFF, int(e[l]) >> 16
+                b, tl = wslot[ws]
+                a, tp = yslot[ys]
+                assert tl <= t - lat and tp <= t - 1 and b >= 0
+                assert iidx[a] == iidx[b] and b <= a
+                blk = int(jidx[a]) * (int(jidx[a]) + 1) // 2 + int(jidx[b])
+                assert blk0 <= blk < blk0 + nblk and lane_blk[l] == blk - blk0
+                assert (a, b) not in seen
+                seen.add((a, b))
+            for q in jobs[job0 + jb: job0 + je]:
+                a, pt, sl, earow = (int(x) for x in q)
+                assert iidx[a] == pt and wslot[sl & 0xFFFF] == (a, t)
+                assert nw + (sl >> 16) < nslots
+                yslot[sl >> 16] = (a, t + 1)
+                if earow >= 0:
+                    assert earow == jidx[a] - row0 < nrows and a not in ea_seen
+                    ea_seen.add(a)
+                else:
+                    d = int(jidx[a]) * (int(jidx[a]) + 3) // 2
+                    assert not (blk0 <= d < blk0 + nblk)
+    if full:
+        want = int(((np.arange(len(iidx)) - ptr[iidx]) + 1).sum())
+        assert len(seen) == want == plan["products"]
+        assert len(ea_seen) == len(iidx)
+    return plan
+
+
+def test_ring_plan_small(problems):
+    for name in ("7cams", "54cams"):
+        pr = problems[name]
+        _replay_ring_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+
+
+def test_ring_plan_venice_shaped():
+    from psba_amd import synth
+    pr = synth.venice_shaped()
+    plan = _replay_ring_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]), max_wgs=6)
+    assert len(plan["wg"]) == 256
+    # the schedule should keep most lanes busy on a realistic problem
+    assert plan["products"] / plan["lane_steps"] > 0.6
+
+
 def test_writer_round_trip(tmp_path):
     """psba_write_problem (the writer the reference declares and comments out,
     PSBA/readparams.h:13-25) -> psba_read_problem: the same problem, with the local rotation
