@@ -202,7 +202,9 @@ void psba_lm_default_options(psba_lm_options *o);
 int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res, double *log);
 
 /* ---- the trust-region caller, PSBA/trust_region.cpp:49-595, and its extra operators -------
- * (single rank; B = 2 J^T J, g = -2 J^T e through psba_linearize(h, 2, -2)). */
+ * (B = 2 J^T J, g = -2 J^T e through psba_linearize(h, 2, -2); with a communicator the points may be
+ * sharded: psba_jmul_dots sums its dot products over the ranks, psba_get_gradient returns the
+ * complete g_a, the modified Cholesky runs replicated on the all-reduced S). */
 /* compute_Jmultiply (PSBA/sba_func.cpp:19-75, CL_files/compute_Jmultiply.cl:6-52): J x for a host
  * vector x[nT].  Jmul has 2 values per OBSERVATION (2 * n2Dprojs, observation order) -- the
  * non-zeros, in the same order, of the reference's dense nP x nC x 2 grid. */
@@ -210,6 +212,10 @@ int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul);
 /* what the loop needs of it: dots = (Jx1.Jx1, Jx1.Jx2, Jx2.Jx2); x2 NULL = x1
  * (trust_region.cpp:125-126,166-176,209-211 take these dot products on the host) */
 int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dots[3]);
+/* v[0..n) (n <= 8) summed over the ranks of the communicator, in place; no communicator: untouched.
+ * What a host loop over sharded points needs for its inner products: the point parts of two
+ * vectors are rank-local, so a dot product is (camera part) + sum over ranks of (point part). */
+int psba_allreduce_scalars(psba_handle h, double *v, int n);
 /* g = [g_a ; g_b] of the last linearization (the host output of compute_g, sba_func.h:103-109) */
 int psba_get_gradient(psba_handle h, double *g);
 /* dp = [dpa ; dpb] of the last solve + back-substitution (host output of compute_dpb) */
@@ -231,6 +237,8 @@ typedef struct {
   int start_itno;
   int verbose;      /* print the reference's per-step line (trust_region.cpp:250) */
   int log_cap;      /* rows available in log (6 doubles each), 0 = none */
+  double init_lambda; /* damping the loop starts with; 0 = the reference's (trust_region.cpp:95-96), where the
+                         first factorization of the gauge-free S fails and the modified Cholesky picks lambda */
 } psba_tr_options;
 
 typedef struct {

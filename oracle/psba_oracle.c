@@ -900,7 +900,7 @@ int orc_trust_region(int nC, int nP, int nO, const double *K, const double *impt
   double *newpts = xmalloc(sizeof(double) * (size_t)nB);
   double *exn = xmalloc(sizeof(double) * 2 * (size_t)nO);
   memset(res, 0, sizeof(*res));
-  double dk = 1, lambda = 0, origin_lambda = 0; /* :95-96 */
+  double dk = 1, lambda = opts->init_lambda, origin_lambda = 0; /* :95-96 */
   int nu = 2, notgood = 0, good_iters = 0, itno = opts->start_itno, nlog = 0, tries = 0;
   int flag = ORC_ITER_CONTINUE;
 

@@ -150,6 +150,7 @@ typedef struct {
   int start_itno;
   int verbose;
   int log_cap;      /* rows of 6 doubles */
+  double init_lambda; /* 0 = the reference's start (PSBA/trust_region.cpp:95-96); a test knob otherwise */
 } orc_tr_opts;
 
 typedef struct {

@@ -42,7 +42,8 @@ class LmResult(C.Structure):
 
 
 class TrOptions(C.Structure):
-    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int)]
+    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int),
+                ("init_lambda", C.c_double)]
 
 
 class TrResult(C.Structure):
@@ -131,6 +132,7 @@ SIGNATURES = [
     ("psba_solve", C.c_int, [_h, C.c_int, C.c_int, C.POINTER(SolveResult)]),
     ("psba_write_problem", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
     ("psba_convert_bal", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dp]),
+    ("psba_allreduce_scalars", C.c_int, [_h, _dp, C.c_int]),
     ("psba_schur_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
@@ -487,8 +489,8 @@ class Psba:
         self._ck(lib.psba_cholmod_lambda(self._h, int(reassemble), C.byref(lam), _d(info)))
         return lam.value, info
 
-    def trust_region(self, max_iter=50, start_itno=0, verbose=False, log_cap=512):
-        opts = TrOptions(max_iter, start_itno, int(verbose), log_cap)
+    def trust_region(self, max_iter=50, start_itno=0, verbose=False, log_cap=512, init_lambda=0.0):
+        opts = TrOptions(max_iter, start_itno, int(verbose), log_cap, init_lambda)
         res = TrResult()
         log = np.zeros((max(log_cap, 1), 6))
         self._ck(lib.psba_trust_region(self._h, C.byref(opts), C.byref(res), _d(log)))

@@ -771,15 +771,28 @@ int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dot
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
   if (!x1 || !dots) return fail(h, PSBA_E_INVALID, "psba_jmul_dots: null pointer");
-  if (h->nranks > 1) return fail(h, PSBA_E_INVALID, "the trust-region operators are single-rank");
   TRY(ensure_trv(h));
   const size_t bytes = sizeof(double) * (size_t)h->d.nT;
   PSBA_HIP(h, hipMemcpyAsync(h->trv[0], x1, bytes, hipMemcpyHostToDevice, h->stream));
   if (x2 && x2 != x1) PSBA_HIP(h, hipMemcpyAsync(h->trv[1], x2, bytes, hipMemcpyHostToDevice, h->stream));
   TRY(launch_jmul(h, h->trv[0], (x2 && x2 != x1) ? h->trv[1] : h->trv[0], nullptr, h->scal + SC_TR_DOTS));
+  // the dot products run over observations: with points sharded over ranks, the sum of the ranks'
+  // (a rank layout without a communicator returns this rank's part)
+  if (h->comm)
+    RCCL(h, ncclAllReduce(h->scal + SC_TR_DOTS, h->scal + SC_TR_DOTS, 3, ncclDouble, ncclSum, h->comm, h->stream));
   TRY(fetch_scalars(h));
   for (int k = 0; k < 3; k++) dots[k] = h->h_scal[SC_TR_DOTS + k];
   return PSBA_OK;
+}
+
+int psba_allreduce_scalars(psba_handle h, double *v, int n) {
+  CHECK_H(h);
+  if (!v || n < 0 || n > 8) return fail(h, PSBA_E_INVALID, "psba_allreduce_scalars: at most 8 values");
+  if (!h->comm || n == 0) return PSBA_OK;  // one rank (or the caller sums): nothing to add
+  double *tmp = h->scal + SC_SUMS;
+  PSBA_HIP(h, hipMemcpyAsync(tmp, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  RCCL(h, ncclAllReduce(tmp, tmp, (size_t)n, ncclDouble, ncclSum, h->comm, h->stream));
+  return d2h(h, v, tmp, sizeof(double) * (size_t)n);
 }
 
 int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul) {
@@ -799,6 +812,8 @@ int psba_get_gradient(psba_handle h, double *g) {
   if (!g) return PSBA_E_INVALID;
   TRY(ensure_trv(h));
   TRY(launch_pack_g(h, h->trv[0]));
+  // g_a is a sum over observations: every rank holds its points' part (g_b is rank-local by nature)
+  if (h->comm) RCCL(h, ncclAllReduce(h->trv[0], h->trv[0], (size_t)h->d.nA, ncclDouble, ncclSum, h->comm, h->stream));
   return d2h(h, g, h->trv[0], sizeof(double) * (size_t)h->d.nT);
 }
 
@@ -822,7 +837,8 @@ int psba_set_step(psba_handle h, const double *dp) {
 int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  if (h->nranks > 1) return fail(h, PSBA_E_INVALID, "the trust-region operators are single-rank");
+  if (h->nranks > 1 && !h->comm)
+    return fail(h, PSBA_E_INVALID, "psba_cholmod_lambda on a rank layout needs the communicator (S must be complete)");
   if (reassemble) {
     // S at lambda = 0 again (the failed factorization worked in place), then the modified
     // Cholesky on a copy of it (trust_region.cpp:341-363)
@@ -830,7 +846,7 @@ int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *i
     TRY(launch_schur(h, 0.0, false));
     // with a communicator (even of one rank) the sums sit in the packed buffer until the all-reduce
     // and k_schur_expand have run: the modified Cholesky must not factor a stale square
-    if (h->packed_pending) TRY(allreduce_schur(h));
+    if (h->packed_pending || h->comm) TRY(allreduce_schur(h));  // every rank then factors the same complete S
   }
   h->diag_done = false;  // the first diagonal block's factor in chol_L is about to be overwritten
   TRY(launch_cholmod(h, h->scal + SC_CHOLMOD));

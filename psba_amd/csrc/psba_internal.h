@@ -16,7 +16,7 @@ constexpr int TILE_OBS = 256;   // observations per point-aligned tile (= thread
 constexpr int TILE_PTS = 128;   // points per tile (bounds the per-point LDS rows)
 constexpr int MAX_GROUPS = 128; // row-aligned groups of the LDS-resident S partition (K2) are tried up to this count, then ranges of blocks
 constexpr int CAM_ACC = 27;     // per-camera accumulators: 21 (sym U) + 6 (g_a)
-constexpr int NSCAL = 96;       // device scalar block (doubles)
+constexpr int NSCAL = 104;      // device scalar block (doubles)
 constexpr int SC_NPART = 16;    // K3's four sums arrive in 16 partial sets (same-address atomics serialise)
 
 // slots of the device scalar block
@@ -33,6 +33,7 @@ enum {
   SC_STATUS_SPD = 81,  // K3: 1.0 when the Cholesky of this try failed
   SC_TR_DOTS = 84,     // trust-region operators: (Jx1.Jx1, Jx1.Jx2, Jx2.Jx2)
   SC_CHOLMOD = 88,     // modified Cholesky: lambda, delta, beta, block columns on the one-column route
+  SC_SUMS = 96,        // psba_allreduce_scalars: up to 8 host scalars summed over the ranks
 };
 
 struct Dims {

@@ -20,59 +20,69 @@ extern "C" int psba_get_gradient(psba_handle h, double *g);
 extern "C" int psba_get_dp(psba_handle h, double *dp);
 extern "C" int psba_set_step(psba_handle h, const double *dp);
 extern "C" int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3);
+extern "C" int psba_allreduce_scalars(psba_handle h, double *v, int n);
 
 namespace {
 
-double dot_n(size_t n, const double *a, const double *b) {  // PSBA/misc.cpp dotProduct
-  double s = 0;
-  for (size_t i = 0; i < n; i++) s += a[i] * b[i];
-  return s;
+// Inner products of parameter vectors [cameras ; points] (PSBA/misc.cpp dotProduct).  With the points
+// sharded over ranks the camera parts are the same on every rank and the point parts add up: K products
+// at once, one small collective (none on a single rank).
+template <int K>
+int dots(psba_handle h, size_t nA, size_t nT, const double *const (&x)[K], const double *const (&y)[K], double (&out)[K]) {
+  double pts[K];
+  for (int k = 0; k < K; k++) {
+    double c = 0, q = 0;
+    for (size_t i = 0; i < nA; i++) c += x[k][i] * y[k][i];
+    for (size_t i = nA; i < nT; i++) q += x[k][i] * y[k][i];
+    out[k] = c;
+    pts[k] = q;
+  }
+  const int rc = psba_allreduce_scalars(h, pts, K);
+  for (int k = 0; k < K; k++) out[k] += pts[k];
+  return rc;
 }
 
-// trust_region.cpp:520-595 (compute_p_2): the minimiser of the quadratic model over
-// span{P_U, P_B} when it lies inside the region, else the dog-leg path.
-double tr_step(size_t n, double uBu, double uBb, double bBb, double delta, const double *PU, const double *PB,
-               double *p, const double *g) {
-  const double ug = dot_n(n, PU, g), bg = dot_n(n, PB, g);
-  const double det = -uBb * uBb + bBb * uBu;
-  const double eta1 = (bg * uBb) / det - (bBb * ug) / det;
-  const double eta2 = (ug * uBb) / det - (bg * uBu) / det;
-  double nrm = 0;
-  for (size_t i = 0; i < n; i++) {
-    p[i] = eta1 * PU[i] + eta2 * PB[i];
-    nrm += p[i] * p[i];
+// The step inside the trust region (what the reference's compute_p_2 returns, PSBA/trust_region.cpp:
+// 520-595), written from the mathematics.  Model: m(p) = g^T p + p^T B p / 2 with B = 2 J^T J.
+// Every candidate is a combination p = alpha P_U + beta P_B of the Cauchy step P_U and the
+// Gauss-Newton step P_B, so five inner products decide everything:
+//  1. the minimiser of m over span{P_U, P_B}: the 2x2 system  [uBu uBb; uBb bBb] (a, b)^T = -(u.g, b.g)^T;
+//     taken when it lies inside the region (|p|^2 = a^2 u.u + 2 a b u.b + b^2 b.b);
+//  2. else the dog-leg path: the Cauchy direction cut at the boundary when P_U alone leaves the
+//     region, P_B when it is inside, else the point of the segment P_U -> P_B on the boundary:
+//     |P_U + s (P_B - P_U)|^2 = delta^2, the root s in [0, 1] of  (d.d) s^2 + 2 (u.d) s + (u.u - delta^2) = 0,
+//     d = P_B - P_U.
+// Returns |p|; p = alpha P_U + beta P_B.
+double tr_step(double uBu, double uBb, double bBb, double delta, double uu, double ub, double bb, double ug, double bg,
+               double &alpha, double &beta) {
+  double len;
+  {
+    const double det = uBu * bBb - uBb * uBb;  // Cramer on the 2x2 Gram system of B
+    alpha = (uBb * bg - bBb * ug) / det;
+    beta = (uBb * ug - uBu * bg) / det;
+    len = std::sqrt(alpha * alpha * uu + 2 * alpha * beta * ub + beta * beta * bb);
   }
-  nrm = std::sqrt(nrm);
-  if (!(nrm > delta)) return nrm;
-  double nu = 0, nb = 0;
-  for (size_t i = 0; i < n; i++) {
-    nu += PU[i] * PU[i];
-    nb += PB[i] * PB[i];
+  if (len > delta) {  // (a NaN minimiser -- singular Gram matrix -- is taken as is, as the reference's comparison does)
+    const double lu = std::sqrt(uu), lb = std::sqrt(bb);
+    if (lu > delta) {
+      alpha = delta / lu;
+      beta = 0;
+      len = delta;
+    } else if (lb <= delta) {  // (the reference returns sqrt(|p|^2 + |P_B|^2) here: a value it only prints)
+      alpha = 0;
+      beta = 1;
+      len = lb;
+    } else {
+      const double dd = uu - 2 * ub + bb, ud = ub - uu, c = uu - delta * delta;
+      double disc = ud * ud - dd * c;
+      if (disc < 0.25e-12) disc = 0;  // (the reference zeroes |b^2 - 4ac| < 1e-12; a negative value is rounding)
+      const double sgm = (-ud + std::sqrt(disc)) / dd;
+      alpha = 1 - sgm;
+      beta = sgm;
+      len = delta;
+    }
   }
-  nu = std::sqrt(nu);
-  nb = std::sqrt(nb);
-  if (nu > delta) {
-    for (size_t i = 0; i < n; i++) p[i] = delta * PU[i] / nu;
-    return delta;
-  }
-  if (nb <= delta) {  // (the reference returns sqrt(nrm + nb^2) here: a value it only prints)
-    for (size_t i = 0; i < n; i++) p[i] = PB[i];
-    return nb;
-  }
-  double a = 0, b = 0, c = 0;
-  for (size_t i = 0; i < n; i++) {
-    const double Ai = PB[i] - PU[i], Bi = 2 * PU[i] - PB[i];
-    a += Ai * Ai;
-    b += Ai * Bi;
-    c += Bi * Bi;
-  }
-  b = 2 * b;
-  c = c - delta * delta;
-  double disc = b * b - 4 * a * c;
-  if (std::fabs(disc) < 1e-12) disc = 0;
-  const double tau = (-b + std::sqrt(disc)) / (2 * a);
-  for (size_t i = 0; i < n; i++) p[i] = PU[i] + (tau - 1) * (PB[i] - PU[i]);
-  return delta;
+  return len;
 }
 
 }  // namespace
@@ -85,6 +95,7 @@ void psba_tr_default_options(psba_tr_options *o) {
   o->start_itno = 0;
   o->verbose = 0;
   o->log_cap = 0;
+  o->init_lambda = 0.0;
 }
 
 int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result *res, double *log) {
@@ -100,9 +111,9 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
   } while (0)
   int nC = 0, nP = 0, nO = 0;
   TR_TRY(psba_get_dims(h, &nC, &nP, &nO));
-  const size_t nT = (size_t)6 * nC + (size_t)3 * nP;
+  const size_t nA = (size_t)6 * nC, nT = nA + (size_t)3 * nP;
   std::vector<double> g(nT), PU(nT), PB(nT), P(nT);
-  double dk = 1, lambda = 0, origin_lambda = 0;  // :95-96
+  double dk = 1, lambda = opts->init_lambda, origin_lambda = 0;  // :95-96
   int nu = 2, notgood = 0, good_iters = 0, itno = opts->start_itno, nlog = 0, tries = 0, chol_fail = 0;
   int flag = PSBA_ITER_CONTINUE;
   double ex_L2 = 0;
@@ -116,7 +127,12 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
     TR_TRY(psba_get_gradient(h, g.data()));
     double d3[3];
     TR_TRY(psba_jmul_dots(h, g.data(), nullptr, d3));  // :125
-    const double gtBg = 2 * d3[0], gtg = dot_n(nT, g.data(), g.data());
+    double gtg1[1];
+    {
+      const double *const xs[1] = {g.data()};
+      TR_TRY(dots<1>(h, nA, nT, xs, xs, gtg1));
+    }
+    const double gtBg = 2 * d3[0], gtg = gtg1[0];
     for (size_t i = 0; i < nT; i++) PU[i] = -(g[i] * gtg) / gtBg;  // :128-130 Cauchy step
     bool solved = false;
     while (!solved) {  // :141-163 around compute_PB (:292-405)
@@ -158,10 +174,18 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
     if (stop) break;
     TR_TRY(psba_jmul_dots(h, PU.data(), PB.data(), d3));  // :166-176
     const double uBu = 2 * d3[0], uBb = 2 * d3[1], bBb = 2 * d3[2];
+    double ip[5];  // u.u, u.b, b.b, u.g, b.g
+    {
+      const double *const xs[5] = {PU.data(), PU.data(), PB.data(), PU.data(), PB.data()};
+      const double *const ys[5] = {PU.data(), PB.data(), PB.data(), g.data(), g.data()};
+      TR_TRY(dots<5>(h, nA, nT, xs, ys, ip));
+    }
     flag = PSBA_ITER_CONTINUE;
     while (flag == PSBA_ITER_CONTINUE) {  // :180-277
       tries++;
-      const double p_norm = tr_step(nT, uBu, uBb, bBb, dk, PU.data(), PB.data(), P.data(), g.data());
+      double alpha, beta;
+      const double p_norm = tr_step(uBu, uBb, bBb, dk, ip[0], ip[1], ip[2], ip[3], ip[4], alpha, beta);
+      for (size_t i = 0; i < nT; i++) P[i] = alpha * PU[i] + beta * PB[i];
       TR_TRY(psba_set_step(h, P.data()));  // dp_buffer <- P, compute_newp (:183-187)
       double act = 0;
       TR_TRY(psba_residual(h, PSBA_PARAMS_NEW, &act));  // :192-194
@@ -171,7 +195,7 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
       }
       TR_TRY(psba_jmul_dots(h, P.data(), nullptr, d3));  // :209-213
       const double Jx_norm = 2 * d3[0];
-      const double pred = dot_n(nT, g.data(), P.data()) + ex_L2 + Jx_norm / 2;
+      const double pred = alpha * ip[3] + beta * ip[4] + ex_L2 + Jx_norm / 2;  // g.p = alpha u.g + beta b.g
       const double rho = (ex_L2 - act) / (ex_L2 - pred);  // :221-222
       bool accepted = false;
       if (rho < 0.25 || act > ex_L2) {

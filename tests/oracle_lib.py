@@ -138,7 +138,8 @@ class Oracle:
 
 
 class TrOpts(C.Structure):
-    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int)]
+    _fields_ = [("max_iter", C.c_int), ("start_itno", C.c_int), ("verbose", C.c_int), ("log_cap", C.c_int),
+                ("init_lambda", C.c_double)]
 
 
 class TrResult(C.Structure):
@@ -165,9 +166,9 @@ def cholmod(A):
     return L, E, d.value, b.value
 
 
-def trust_region(o, max_iter=50, start_itno=0, log_cap=512, verbose=False):
+def trust_region(o, max_iter=50, start_itno=0, log_cap=512, verbose=False, init_lambda=0.0):
     """orc_trust_region on the Oracle instance o (its cams / pts are updated in place)."""
-    opts = TrOpts(max_iter, start_itno, int(verbose), log_cap)
+    opts = TrOpts(max_iter, start_itno, int(verbose), log_cap, init_lambda)
     res = TrResult()
     log = np.zeros((max(log_cap, 1), 6))
     _tr(o.nC, o.nP, o.nO, o.K, o.impts, o.initrot, o.cams, o.pts, o.iidx, o.jidx, C.byref(opts), C.byref(res),
