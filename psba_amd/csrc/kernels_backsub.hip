@@ -80,6 +80,15 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     const int a = o0 + tid;
     const int tn = tile + gridDim.x;
     const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
+    if (o1 - o0 > TILE_OBS) {  // a point seen by more cameras than a tile holds: k_backsub_long's
+      dsc = dn;
+      i = j = 0;
+      if (dsc.z + tid < dsc.w) {
+        i = p.iidx[dsc.z + tid];
+        j = p.jidx[dsc.z + tid];
+      }
+      continue;
+    }
     int pb0 = 0, pb1 = 0;  // CSR bounds of this thread's point
     if (p0 + tid < p1) {
       pb0 = p.ptr[p0 + tid] - o0;
@@ -215,6 +224,97 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
   }
 }
 
+// A point seen by more than TILE_OBS cameras (compute_eb.cl:28-37 loops over all cameras): one
+// workgroup walks its observations twice, TILE_OBS at a time -- sum of W_ij^T dpa_j (from the
+// stored W), then dpb_i and the proposed point by one thread, then the residuals at the proposal.
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_backsub_long(BackArgs p, const int *long_pts) {
+  __shared__ double sRed[TILE_OBS / 64][4];
+  __shared__ double sNP[3];
+  const int tid = threadIdx.x, i = long_pts[blockIdx.x];
+  const int o0 = p.ptr[i], o1 = p.ptr[i + 1];
+  double t3[3] = {0.0, 0.0, 0.0};
+  for (int a = o0 + tid; a < o1; a += TILE_OBS) {
+    const double *w = p.W + 18 * (size_t)a;
+    const double *dw = p.dp + 6 * (size_t)p.jidx[a];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double dk = dw[k];
+      t3[0] += w[3 * k] * dk;
+      t3[1] += w[3 * k + 1] * dk;
+      t3[2] += w[3 * k + 2] * dk;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    double v = t3[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) sRed[tid >> 6][q] = v;
+  }
+  __syncthreads();
+  double s_dp = 0.0, s_den = 0.0, s_cost = 0.0, s_np = 0.0;
+  if (tid == 0) {
+    const double *pv = p.PV + 9 * (size_t)i;
+    double e[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      double v = 0.0;
+      for (int w2 = 0; w2 < TILE_OBS / 64; w2++) v += sRed[w2][q];
+      e[q] = pv[6 + q] - v;
+      if (DUMP) p.dbg_eb[3 * (size_t)i + q] = e[q];
+    }
+    double v[6], vi[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = pv[k];
+    v[0] += p.mu;
+    v[3] += p.mu;
+    v[5] += p.mu;
+    sym3_inverse(v, vi);
+    const double d[3] = {vi[0] * e[0] + vi[1] * e[1] + vi[2] * e[2], vi[1] * e[0] + vi[3] * e[1] + vi[4] * e[2],
+                         vi[2] * e[0] + vi[4] * e[1] + vi[5] * e[2]};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const double n = p.pts[3 * (size_t)i + q] + d[q];
+      p.dp[p.nA + 3 * (size_t)i + q] = d[q];
+      p.newpts[3 * (size_t)i + q] = n;
+      sNP[q] = n;
+      s_dp += d[q] * d[q];
+      s_den += d[q] * (p.mu * d[q] + pv[6 + q]);
+      s_np += n * n;
+    }
+  }
+  __syncthreads();
+  for (int a = o0 + tid; a < o1; a += TILE_OBS) {
+    const int j = p.jidx[a];
+    double cc[9], cam[6], e0, e1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * (size_t)j + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * (size_t)j + k] + p.dp[6 * (size_t)j + k];
+    const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
+    residual_obs(cc, cc + 5, cam, sNP, m.x, m.y, e0, e1);
+    s_cost += e0 * e0 + e1 * e1;
+  }
+  __syncthreads();
+  {
+    double v = s_cost;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) sRed[tid >> 6][3] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0.0;
+    for (int w2 = 0; w2 < TILE_OBS / 64; w2++) c += sRed[w2][3];
+    double *dst = p.scal + SC_PART + 4 * (blockIdx.x % SC_NPART);
+    atomicAdd(&dst[0], s_dp);
+    atomicAdd(&dst[1], s_den);
+    atomicAdd(&dst[2], c);
+    atomicAdd(&dst[3], s_np);
+  }
+}
+
 // the try's scalar block into pinned host memory: one small kernel instead of the runtime's
 // 768-byte device-to-host copy (3.9 us on the stream in front of the linearization queued ahead)
 __global__ __launch_bounds__(128) void k_publish_scal(const double *scal, double *host) {
@@ -275,6 +375,12 @@ int launch_backsub(psba_ctx *h, double mu, bool dump) {
       hipLaunchKernelGGL((k_backsub<false, false>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
     else
       hipLaunchKernelGGL((k_backsub<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+    if (h->nLong) {  // points seen by more cameras than a tile holds
+      if (dump)
+        hipLaunchKernelGGL(k_backsub_long<true>, dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts);
+      else
+        hipLaunchKernelGGL(k_backsub_long<false>, dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts);
+    }
   }
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

@@ -56,6 +56,15 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
     const int a = o0 + tid;
     const int tn = tile + gridDim.x;
     const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
+    if (o1 - o0 > TILE_OBS) {  // a point seen by more cameras than a tile holds: k_linearize_long's
+      dsc = dn;
+      i = j = 0;
+      if (dsc.z + tid < dsc.w) {
+        i = p.iidx[dsc.z + tid];
+        j = p.jidx[dsc.z + tid];
+      }
+      continue;
+    }
     // CSR bounds of the (point, component) tasks of this thread (see below)
     constexpr int NTASK = (9 * TILE_PTS + TILE_OBS - 1) / TILE_OBS;  // rounds of (point, component) tasks
     int pb[NTASK][2];
@@ -173,6 +182,76 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   if (GACC) return;
   double *slab = p.campart + (size_t)blockIdx.x * nAcc;
   for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
+}
+
+// A point seen by more than TILE_OBS cameras (no limit in the reference: compute_V.cl:6-38,
+// compute_g.cl:43-58 loop over all cameras): one workgroup walks its observations, TILE_OBS at a
+// time.  W as in k_linearize; V_i and g_b,i summed over the workgroup; the camera sums go with global
+// fp64 atomics into one extra slab of the per-workgroup camera sums (zeroed before the launch) that
+// k_cam_reduce adds like any other -- with GACC the camera-major pass covers these observations anyway.
+template <bool DUMP, bool GACC>
+__global__ __launch_bounds__(TILE_OBS) void k_linearize_long(LinArgs p, const int *long_pts, double *cam_slab) {
+  __shared__ double sRed[TILE_OBS / 64][9];
+  const int tid = threadIdx.x, i = long_pts[blockIdx.x];
+  const int o0 = p.ptr[i], o1 = p.ptr[i + 1];
+  double M[3], acc[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++) M[k] = p.pts[3 * (size_t)i + k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0.0;
+  for (int a = o0 + tid; a < o1; a += TILE_OBS) {
+    const int j = p.jidx[a];
+    double cc[9], cam[6], e[2], A[12], B[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * (size_t)j + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * (size_t)j + k];
+    const double2 m = reinterpret_cast<const double2 *>(p.impts)[a];
+    linearize_obs(cc, cc + 5, cam, M, m.x, m.y, e, A, B);
+    if (DUMP) {
+      p.dbg_ex[2 * (size_t)a] = e[0];
+      p.dbg_ex[2 * (size_t)a + 1] = e[1];
+#pragma unroll
+      for (int k = 0; k < 12; k++) p.dbg_JA[12 * (size_t)a + k] = A[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) p.dbg_JB[6 * (size_t)a + k] = B[k];
+    }
+    double *w = p.W + 18 * (size_t)a;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) w[3 * r + c] = p.coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = r; c < 3; c++) acc[k++] += B[r] * B[c] + B[3 + r] * B[3 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) acc[6 + r] += B[r] * e[0] + B[3 + r] * e[1];
+    if (!GACC) {
+      double *cs = cam_slab + CAM_ACC * (size_t)j;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) atomicAdd(&cs[q++], A[r] * A[c] + A[6 + r] * A[6 + c]);
+#pragma unroll
+      for (int r = 0; r < 6; r++) atomicAdd(&cs[21 + r], A[r] * e[0] + A[6 + r] * e[1]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) sRed[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double v = 0.0;
+    for (int q = 0; q < TILE_OBS / 64; q++) v += sRed[q][tid];
+    p.PV[9 * (size_t)i + tid] = (tid < 6 ? p.coeff : p.coeff_g) * v;
+  }
 }
 
 // GACC: U_j = sum_i A_ij^T A_ij and g_a,j = sum_i A_ij^T e_ij (compute_U.cl:22-29, compute_g.cl:29-41)
@@ -382,6 +461,12 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
         hipLaunchKernelGGL((k_linearize<true, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
       else
         hipLaunchKernelGGL((k_linearize<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      if (h->nLong) {
+        if (dump)
+          hipLaunchKernelGGL((k_linearize_long<true, true>), dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts, (double *)nullptr);
+        else
+          hipLaunchKernelGGL((k_linearize_long<false, true>), dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts, (double *)nullptr);
+      }
       hipLaunchKernelGGL(k_cam_sums, dim3((h->nCamUnits + 3) / 4), dim3(256), 0, h->stream, a, h->cam_obs,
                          h->cam_units, h->nCamUnits);
       hipLaunchKernelGGL(k_cam_finalize, dim3((42 * d.nC + 255) / 256), dim3(256), 0, h->stream, h->camacc, d.nC,
@@ -391,7 +476,17 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
         hipLaunchKernelGGL((k_linearize<true, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
       else
         hipLaunchKernelGGL((k_linearize<false, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
-      hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, h->nPart, d.nC, h->coeff,
+      int nslab = h->nPart;
+      if (h->nLong) {  // their camera sums: one more slab
+        double *slab = h->campart + (size_t)h->nPart * d.nC * CAM_ACC;
+        PSBA_HIP(h, hipMemsetAsync(slab, 0, sizeof(double) * CAM_ACC * (size_t)d.nC, h->stream));
+        if (dump)
+          hipLaunchKernelGGL((k_linearize_long<true, false>), dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts, slab);
+        else
+          hipLaunchKernelGGL((k_linearize_long<false, false>), dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts, slab);
+        nslab++;
+      }
+      hipLaunchKernelGGL(k_cam_reduce, dim3(d.nC), dim3(1024), 0, h->stream, h->campart, nslab, d.nC, h->coeff,
                          h->coeff_g, Uo, gao);
     }
   }

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
     const int p0 = p.tile_pt[tile], p1 = p.tile_pt[tile + 1];
     const int o0 = p.ptr[p0], o1 = p.ptr[p1];
     const int nobs = o1 - o0;
+    if (nobs > TILE_OBS) continue;  // a point seen by more cameras than a tile holds: k_schur_long's
     __syncthreads();
     // coalesced copy of the tile's W blocks
     {
@@ -119,6 +120,58 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_atomic(SchurArgs p) {
   __syncthreads();
   for (int t = tid; t < p.nA; t += TILE_OBS)
     if (sEa[t] != 0.0) atomicAdd(&p.ea[t], sEa[t]);
+}
+
+// (v1 path) a point seen by more than TILE_OBS cameras (no such limit in compute_S.cl:39-52): one
+// workgroup, every thread the products Y_a W_b^T, b <= a, of its observations a, straight into S
+// and e_a with global fp64 atomics.
+template <bool DUMP>
+__global__ __launch_bounds__(TILE_OBS) void k_schur_long(SchurArgs p, const int *long_pts) {
+  const int tid = threadIdx.x, i = long_pts[blockIdx.x];
+  const int o0 = p.ptr[i], o1 = p.ptr[i + 1];
+  const double *pv = p.PV + 9 * (size_t)i;
+  double v[6], vi[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) v[k] = pv[k];
+  v[0] += p.mu;
+  v[3] += p.mu;
+  v[5] += p.mu;
+  if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
+  const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+  if (DUMP && tid == 0) {
+    double *o = p.dbg_Vinv + 9 * (size_t)i;
+    o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
+    o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
+    o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
+  }
+  for (int a = o0 + tid; a < o1; a += TILE_OBS) {
+    const int ja = p.jidx[a];
+    const double *w = p.W + 18 * (size_t)a;
+    double Y[18];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+      Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+      Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+      Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+      atomicAdd(&p.ea[6 * ja + r], -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2));
+    }
+    if (DUMP) {
+#pragma unroll
+      for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
+    }
+    for (int b = o0; b <= a; b++) {
+      double *Sblk = p.S + (size_t)(6 * ja) * p.ld + 6 * p.jidx[b];
+      const double *wb = p.W + 18 * (size_t)b;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+          atomicAdd(&Sblk[(size_t)r * p.ld + c], -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
+      }
+    }
+  }
 }
 
 // v4: the lower block triangle of S is split into groups of blocks (whole camera rows, or ranges
@@ -725,10 +778,18 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
         o.ld = h->n32;
         o.try_id = h->try_id;
         hipLaunchKernelGGL(k_schur_owner, dim3((h->own_nwaves + 3) / 4), dim3(256), 0, h->stream, o);
-      } else if (dump)
-        hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
-      else
-        hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+      } else {
+        if (dump)
+          hipLaunchKernelGGL(k_schur_atomic<true>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+        else
+          hipLaunchKernelGGL(k_schur_atomic<false>, dim3(grid), dim3(TILE_OBS), lds, h->stream, a);
+        if (h->nLong) {
+          if (dump)
+            hipLaunchKernelGGL(k_schur_long<true>, dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts);
+          else
+            hipLaunchKernelGGL(k_schur_long<false>, dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts);
+        }
+      }
     }
     {
       ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR_REDUCE);

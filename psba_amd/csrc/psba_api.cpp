@@ -116,6 +116,8 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->params0);
   dev_free(h->tile_pt);
   dev_free(h->tile_desc);
+  dev_free(h->long_pts);
+  h->nLong = 0;
   dev_free(h->W);
   dev_free(h->W_alt);
   dev_free(h->PV_alt);
@@ -264,16 +266,22 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     if (ptr[(size_t)i + 1] > maxTrack) maxTrack = ptr[(size_t)i + 1];
     ptr[(size_t)i + 1] += ptr[i];
   }
-  if (maxTrack > TILE_OBS)
-    return fail(h, PSBA_E_INVALID, "a point is seen by %d cameras; at most %d supported", maxTrack,
-                TILE_OBS);
-  std::vector<int> tile_pt;
+  // point-aligned tiles of at most TILE_OBS observations / TILE_PTS points.  A point seen by more
+  // cameras than a tile holds (the reference has no such limit: CL_files/compute_V.cl:6-38 loops
+  // over all cameras) is a tile of its own that the tile kernels skip; one workgroup per such point
+  // walks its observations in the *_long kernels instead.
+  std::vector<int> tile_pt, long_pts;
   tile_pt.push_back(0);
   {
     int p0 = 0;
     while (p0 < n3Dpts) {
       int p1 = p0;
-      while (p1 < n3Dpts && (ptr[(size_t)p1 + 1] - ptr[p0]) <= TILE_OBS && (p1 - p0) < TILE_PTS) p1++;
+      if (ptr[(size_t)p0 + 1] - ptr[p0] > TILE_OBS) {
+        long_pts.push_back(p0);
+        p1 = p0 + 1;
+      } else {
+        while (p1 < n3Dpts && (ptr[(size_t)p1 + 1] - ptr[p0]) <= TILE_OBS && (p1 - p0) < TILE_PTS) p1++;
+      }
       tile_pt.push_back(p1);
       p0 = p1;
     }
@@ -318,6 +326,11 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->ptr, (size_t)d.nP + 1));
   TRY(dev_alloc(h, &h->tile_pt, tile_pt.size()));
   TRY(dev_alloc(h, &h->tile_desc, (size_t)d.nTiles));
+  h->nLong = (int)long_pts.size();
+  if (h->nLong) {
+    TRY(dev_alloc(h, &h->long_pts, long_pts.size()));
+    PSBA_HIP(h, hipMemcpy(h->long_pts, long_pts.data(), sizeof(int) * long_pts.size(), hipMemcpyHostToDevice));
+  }
   TRY(dev_alloc(h, &h->W, (size_t)18 * d.nO));
   TRY(dev_alloc(h, &h->W_alt, (size_t)18 * d.nO));
   TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
@@ -327,7 +340,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
   TRY(dev_alloc(h, &h->ga_alt, (size_t)d.nA));
   h->ahead = h->lin_is_ahead = false;
-  TRY(dev_alloc(h, &h->campart, h->cam_global ? 1 : (size_t)h->nPart * d.nC * CAM_ACC));
+  TRY(dev_alloc(h, &h->campart, h->cam_global ? 1 : (size_t)(h->nPart + 1) * d.nC * CAM_ACC));  // (+1: the long points' slab)
   if (h->cam_global) {
     TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * CAM_ACC));
     // camera-major index of the observations, cut into segments of at most 256

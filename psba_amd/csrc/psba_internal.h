@@ -148,6 +148,8 @@ struct psba_ctx {
   int *jidx = nullptr;          // [nO] camera of each observation   (jidx_buffer)
   int *ptr = nullptr;           // [nP+1] point CSR over observations (replaces blkIdx_buffer)
   int *tile_pt = nullptr;       // [nTiles+1] first point of each tile
+  int *long_pts = nullptr;      // [nLong] points seen by more than TILE_OBS cameras (tiles of their own, handled by the *_long kernels)
+  int nLong = 0;
   int4 *tile_desc = nullptr;    // [nTiles] (first point, end point, first observation, end observation): one load instead of a chain
   double *W = nullptr;          // [nO][18] W_ij = coeff A^T B        (W_buffer)
   double *PV = nullptr;         // [nP][9]  V_i sym6 | g_b,i          (V_buffer + g_buffer tail)

@@ -364,6 +364,79 @@ def test_owner_route_beyond_the_lds_limit_of_the_atomic_kernel():
     h.close()
 
 
+def test_points_seen_by_more_cameras_than_a_tile_holds():
+    """The reference puts no limit on how many cameras see a point (CL_files/compute_V.cl:6-38,
+    compute_eb.cl:28-37 loop over all of them).  The tile kernels hold 256 observations per tile;
+    a longer track is a tile of its own that one workgroup walks (k_linearize_long, k_backsub_long,
+    k_schur_long) and K2 takes the owner route, whose product lists know no distance limit.  Two
+    points seen by 300 of 400 cameras among 300 ordinary ones: every intermediate against the oracle."""
+    import psba_amd
+    import psba_amd.synth as synth
+    from psba_amd.capi import Problem
+    base = synth.make_problem(n_cams=400, n_pts=300, mean_track=5.0, seed=4242)
+    lng = synth.make_problem(n_cams=400, n_pts=2, mean_track=300.0, seed=4242, min_track=300, max_track=300, shard=1)
+    assert np.array_equal(base["K"], lng["K"]) and np.array_equal(base["cams"], lng["cams"])
+    # one long point in the middle of the sequence, one at the end
+    cut = 150
+    ocut = int(np.searchsorted(base["iidx"], cut))
+    def cat(a, b, c, d):
+        return np.concatenate([a, b, c, d])
+    l0 = lng["iidx"] == 0
+    iidx = cat(base["iidx"][:ocut], np.full(300, cut, np.int32), base["iidx"][ocut:] + 1, np.full(300, 301, np.int32))
+    jidx = cat(base["jidx"][:ocut], lng["jidx"][l0], base["jidx"][ocut:], lng["jidx"][~l0])
+    impts = cat(base["impts"][:ocut], lng["impts"][l0], base["impts"][ocut:], lng["impts"][~l0])
+    pts = np.concatenate([base["pts"][:cut], lng["pts"][:1], base["pts"][cut:], lng["pts"][1:]])
+    prob = Problem(K=base["K"], initrot=base["initrot"], cams=base["cams"], pts=pts, impts=impts,
+                   iidx=iidx.astype(np.int32), jidx=jidx.astype(np.int32), nC=400, nP=302, nO=int(iidx.size))
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    _, dp, eab = o.solve(lin, sch)
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 1
+    close(h.compute_exQT(), lin["ex"], 1e-11, "ex")
+    close(h.compute_U(1.0), lin["U"], 1e-11, "U")
+    close(h.compute_V(1.0), lin["V"], 1e-11, "V")
+    close(h.compute_Wblks(1.0), lin["W"], 1e-11, "W")
+    close(h.compute_g(1.0), lin["g"], 1e-11, "g")
+    h.update_UV(mu)
+    rc, Vinv = h.compute_Vinv()
+    assert rc == 0
+    close(Vinv, sch["Vinv"], 1e-10, "Vinv")
+    close(h.compute_Yblks(), sch["Y"], 1e-10, "Y")
+    close(h.compute_S(), sch["S"], 1e-11, "S (mirror verbs)")
+    close(h.compute_ea(), sch["eab"][: o.nA], 1e-10, "ea")
+    rc, dpa = h.SPDinv_matVec()
+    assert rc == 0
+    close(dpa, dp[: o.nA], 1e-8, "dpa")
+    close(h.compute_eb(), eab[o.nA:], 1e-8, "eb")
+    close(h.compute_dpb(), dp, 1e-8, "dp")
+    h.restore_UVdiag()
+    # the fused verbs: owner route, then K3 with its scalars
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    n32 = (o.nA + 31) // 32 * 32
+    M = h.get_reduce_buffer().reshape(n32 + 1, n32)
+    close(M[: o.nA, : o.nA], sch["S"], 1e-11, "S (fused verb)")
+    close(M[n32, : o.nA], sch["eab"][: o.nA], 1e-10, "ea (fused verb)")
+    h.schur_reduce()
+    h.schur_solve()
+    sc = h.backsub(mu)
+    assert sc.status == 0
+    newp = np.r_[o.cams, o.pts] + dp
+    ex_new = o.exQT(cams=newp[: o.nA], pts=newp[o.nA:])
+    for got, want in [(sc.dp_l2, dp @ dp), (sc.gain_den, dp @ (mu * dp + lin["g"])), (sc.new_cost, ex_new @ ex_new),
+                      (sc.newp_l2, newp @ newp)]:
+        assert abs(got - want) <= 1e-7 * abs(want), (got, want)
+    h.upload_problem(prob)
+    res, _ = h.levmar(max_iter=5, tr_handoff=False)
+    ores, _ = Oracle(prob).levmar(max_iter=5, tr_handoff=False)
+    assert abs(res.final_err - ores.final_err) <= 1e-8 * ores.final_err
+    h.close()
+
+
 def test_levmar_through_failed_first_tries(problems):
     """psba_levmar driven through PSBA_NOT_SPD tries (reference PSBA/levmar.cpp:227-244: mu *= nu,
     nu *= 2, no step): with mu_0 = 1e-30 max diag the first Schur complements are singular to
