@@ -327,6 +327,27 @@ int psba_profile_get(psba_handle h, int kernel, double *total_ms, int *launches)
  * (SURVEY.md section 8(d) formulas; stated in DESIGN.md) */
 int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
 
+/* ---- the dense factorization sharded over ranks (large matrices: the two-level chain) --------------
+ * The reference factors S on one device (PSBA/cl_spdinv.cpp:18-40, CL_files/SPD_inv.cl:165-179).
+ * Here every rank holds the complete S after the all-reduce and factors the super-panels (NB columns)
+ * itself; the K = NB update of everything to their right -- nearly all of the n^3 / 3 flops -- is
+ * shared: a rank updates the 64-column blocks B (columns [64 B, 64 B + 64)) with B % nranks == rank,
+ * and before a super-panel is factored the owners of its blocks send them (rows 64 B .. n32, the
+ * e_a row included, packed row by row) to everybody.  With a communicator psba_schur_solve runs this
+ * by itself (ncclBroadcast; PSBA_CHOL_REPLICATED=1 keeps the factorization replicated); the pieces
+ * below let a host with its own transport -- or a test with several handles -- drive it:
+ *   psba_chol_dist_shape     n32, NB, and whether the matrix is large enough for the sharded chain
+ *   psba_chol_dist_begin     the first diagonal block
+ *   psba_chol_dist_superpanel(J)  the 32-column steps of the super-panel at column J (its columns
+ *                            must be complete on this rank) and this rank's share of the update
+ *   psba_chol_dist_block(B, set, buf, &n)  get (set = 0) / set the packed block B; n = its doubles
+ *   psba_chol_dist_finish    the backward solve: dpa, as after psba_schur_solve */
+int psba_chol_dist_shape(psba_handle h, int *n32, int *NB, int *sharded);
+int psba_chol_dist_begin(psba_handle h);
+int psba_chol_dist_superpanel(psba_handle h, int J);
+int psba_chol_dist_block(psba_handle h, int B, int set, double *buf, long long *n_doubles);
+int psba_chol_dist_finish(psba_handle h);
+
 /* ---- test hook: the static schedule of the S-assembly kernel, built on the host only ----
  * (no device needed).  The reference decides the same placement per launch through its
  * blkIdx_buffer look-ups (CL_files/compute_S.cl:13-22); here it is data that can be checked.

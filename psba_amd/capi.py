@@ -133,6 +133,11 @@ SIGNATURES = [
     ("psba_write_problem", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
     ("psba_convert_bal", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dp]),
     ("psba_allreduce_scalars", C.c_int, [_h, _dp, C.c_int]),
+    ("psba_chol_dist_shape", C.c_int, [_h, _ip, _ip, _ip]),
+    ("psba_chol_dist_begin", C.c_int, [_h]),
+    ("psba_chol_dist_superpanel", C.c_int, [_h, C.c_int]),
+    ("psba_chol_dist_block", C.c_int, [_h, C.c_int, C.c_int, _dp, C.POINTER(C.c_longlong)]),
+    ("psba_chol_dist_finish", C.c_int, [_h]),
     ("psba_schur_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
@@ -463,6 +468,32 @@ class Psba:
         log = np.zeros((max(log_cap, 1), 5))
         self._ck(lib.psba_levmar(self._h, C.byref(opts), C.byref(res), _d(log)))
         return res, log[: res.n_log].copy()
+
+    # ---- the sharded dense factorization, piece by piece ----
+    def chol_dist_shape(self):
+        n32, nb, sh = C.c_int(), C.c_int(), C.c_int()
+        self._ck(lib.psba_chol_dist_shape(self._h, C.byref(n32), C.byref(nb), C.byref(sh)))
+        return n32.value, nb.value, bool(sh.value)
+
+    def chol_dist_begin(self):
+        self._ck(lib.psba_chol_dist_begin(self._h))
+
+    def chol_dist_superpanel(self, J):
+        self._ck(lib.psba_chol_dist_superpanel(self._h, int(J)))
+
+    def chol_dist_get_block(self, B):
+        n = C.c_longlong()
+        self._ck(lib.psba_chol_dist_block(self._h, int(B), 0, None, C.byref(n)))
+        buf = np.empty(n.value)
+        self._ck(lib.psba_chol_dist_block(self._h, int(B), 0, _d(buf), C.byref(n)))
+        return buf
+
+    def chol_dist_set_block(self, B, buf):
+        n = C.c_longlong()
+        self._ck(lib.psba_chol_dist_block(self._h, int(B), 1, _d(_c(buf)), C.byref(n)))
+
+    def chol_dist_finish(self):
+        self._ck(lib.psba_chol_dist_finish(self._h))
 
     # ---- trust region ----
     def compute_Jmultiply(self, x):

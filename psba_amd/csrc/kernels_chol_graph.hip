@@ -440,13 +440,19 @@ __device__ __forceinline__ void wide4_block(double *Lw, const double *Lx, int ld
 // Workgroup 0: the next diagonal block + its factorization and the e_a tile row's first tiles are as
 // in k_cholg_update_wide; every other wave owns one 64x64 block of the lower triangle of the
 // trailing square, or one tile of the e_a tile row.
+// nranks > 1: the factorization is sharded -- this rank updates only the 64-column blocks it owns
+// (absolute block B = column / 64, owner B % nranks; the e_a tiles of those columns with them); the
+// owners send a super-panel's columns to everybody before it is factored (launch_chol_graph), and the
+// next diagonal block is factored after that exchange by k_cholg_diag (workgroup 0's look-ahead would
+// read columns this rank may not own).
 __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *Lx, int ld, int J, int KW, int nT,
-                                                            int Tw, double *linv, int *status) {
+                                                            int Tw, double *linv, int *status, int nranks, int rank) {
   __shared__ Factor32Lds s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   if (blockIdx.x == 0) {
+    if (nranks > 1) return;
     if (tid < 4) s.flag[tid] = 0;
     if (tid == 4) s.fail = 0;
     if (wave < 3) {
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   if (idx >= ntri) {
     const long long e = idx - ntri;  // e_a tile row
     if (e >= nTl) return;
+    if (nranks > 1 && (Tw + (int)e) / 4 % nranks != rank) return;
     const int TC = Tw + (int)e;
     store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
     return;
@@ -478,12 +485,15 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   while ((long long)m * (m + 1) / 2 > idx) m--;
   m = __builtin_amdgcn_readfirstlane(m);
   const int mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+  if (nranks > 1 && (Tw / 4 + mc) % nranks != rank) return;
   const int TR0 = Tw + 4 * m, TC0 = Tw + 4 * mc;
   const int last = nT - 2;  // last tile row / column of the square
+  // (sharded: nobody else forms the next diagonal block's tiles -- its owner does, here)
+  const int Tx = nranks > 1 ? -4 : Tw;
   if (mc < m && TR0 + 3 <= last && (m > 0))
-    wide4_block<true>(Lw, Lx, ld, J, KW, Tw, last, TR0, TC0, li, lk);
+    wide4_block<true>(Lw, Lx, ld, J, KW, Tx, last, TR0, TC0, li, lk);
   else
-    wide4_block<false>(Lw, Lx, ld, J, KW, Tw, last, TR0, TC0, li, lk);
+    wide4_block<false>(Lw, Lx, ld, J, KW, Tx, last, TR0, TC0, li, lk);
 }
 
 // panel (fused chain): trsm + update of the panel at column j in ONE kernel.  Every wave
@@ -841,66 +851,130 @@ __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const dou
   }
 }
 
-static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
-  const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
-  double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
-  // fused panel kernel (with the identity rows riding along) while a panel's tiles (one wave
-  // each, 5x the MFMA work) still fit on the chip's 1024 SIMDs at once; beyond that the
-  // redundant work is no longer free: two kernels per panel and a sequential backward solve
+// the shape of the chain for a matrix size (see enqueue_chain for the measurements behind the limits)
+struct ChainShape {
+  bool fused, blocked, fused2;
+  int NB;
+  long long cols_fused_max;
+};
+static ChainShape chain_shape(const psba_ctx *h) {
+  const int n32 = h->n32, nT = n32 / 16 + 1;
+  ChainShape c;
   const long long M0 = (nT - 1) - GB / 16;
   long long fused_max = 2200;  // i.e. every n32 <= 1024, the size k_cholg_solve<16> holds; against the mid-size chain 100 cameras 0.331 -> 0.295 ms per LM iteration, 110: 199 -> 169 us per solve, 130: 244 -> 217, 150: 290 -> 265
   if (const char *e = getenv("PSBA_CHOL_FUSED_MAX")) fused_max = atoll(e);
-  const bool fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= fused_max && n32 <= 1024;
-  if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
-    hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
-  int NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
-  if (const char *e = getenv("PSBA_CHOL_NB")) NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : NB;
+  c.fused = !getenv("PSBA_CHOL_UNFUSED") && M0 * (M0 + 1) / 2 + M0 <= fused_max && n32 <= 1024;
+  c.NB = n32 >= 8192 ? 384 : 256;  // super-panel width (multiple of 64).  With the 4x4-tile update: n = 12 000 20.3 / 17.6 / 17.1 / 17.1 ms at 128 / 256 / 384 / 512, n = 6000 4.73 / 4.55 / 4.57 ms per LM iteration at 128 / 256 / 384, n = 3600 2.20 / 2.15 / 2.24 (PSBA_CHOL_NB: development knob)
+  if (const char *e = getenv("PSBA_CHOL_NB")) c.NB = atoi(e) >= 64 ? atoi(e) / 32 * 32 : c.NB;
   // (measured, ms per LM iteration flat / two-level with the fused in-block steps: n = 1542 0.867 /
   // 0.884, 2040 1.154 / 1.103, 2400 1.385 / 1.287, 2700 1.636 / 1.469)
-  const bool blocked = !fused && (n32 >= 1792 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
+  c.blocked = !c.fused && (n32 >= 1792 || getenv("PSBA_CHOL_BLOCKED")) && !getenv("PSBA_CHOL_FLAT");
   // mid sizes: the fused panel kernel without the identity rows (one kernel per panel instead of
   // trsm + update: the redundant X pieces cost less than the second launch while the panel has few
   // tiles; per solve n = 600: 218 against 267 us, 780: 292 / 356, 1200: 502 / 564, 1542: 763 / 759,
   // 2040: 1241 / 1070), backward solve through the factor
   long long f2max = 3600;
   if (const char *e = getenv("PSBA_CHOL_FUSED2_MAX")) f2max = atoll(e);
-  const bool fused2 = !fused && !blocked && M0 * (M0 + 1) / 2 <= f2max;
-  long long cols_fused_max = 3000;  // sweep 0 / 3000 / 6000 / 9000 tiles: n = 6000 4.77 / 4.56 / 4.72 / 4.69 ms per LM iteration, n = 12 000 17.85 / 17.63 / 18.19 / 18.80 ms per solve
-  if (const char *e = getenv("PSBA_CHOL_COLS_FUSED_MAX")) cols_fused_max = atoll(e);
-  for (int J = 0; blocked && J < n32; J += NB) {
-    const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
-    for (int j = J; j < JE; j += GB) {
-      const int T0 = (j + GB) / 16, TE = JE / 16;
-      long long tiles = 0;  // tiles of the super-panel's remaining columns, all rows below
-      for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
-      if (j + GB < JE && tiles <= cols_fused_max) {
-        // trsm + update in one kernel (every wave forms the X pieces of its tile itself: 40 MFMAs
-        // per tile instead of 8, which pays while the step has few tiles -- per LM iteration
-        // n = 3600: 2.17 against 2.36 ms, 6000: 4.72 / 4.78, 12 000 (all steps): 19.0 / 17.9)
-        hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nT, 0,
-                           TE, linv, h->status);
-        continue;
-      }
-      hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
-      if (j + GB < JE)
-        hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
-                           nT, TE, linv, h->status);
+  c.fused2 = !c.fused && !c.blocked && M0 * (M0 + 1) / 2 <= f2max;
+  c.cols_fused_max = 3000;  // sweep 0 / 3000 / 6000 / 9000 tiles: n = 6000 4.77 / 4.56 / 4.72 / 4.69 ms per LM iteration, n = 12 000 17.85 / 17.63 / 18.19 / 18.80 ms per solve
+  if (const char *e = getenv("PSBA_CHOL_COLS_FUSED_MAX")) c.cols_fused_max = atoll(e);
+  return c;
+}
+
+// one super-panel [J, J + NB) of the two-level chain: its 32-column steps, which update only the
+// super-panel's remaining columns (all rows below), then ONE K = NB update of everything to its
+// right.  nranks > 1: that update only for this rank's 64-column blocks (k_cholg_update_wide4).
+static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, int J, int nranks, int rank) {
+  const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;
+  double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
+  const int NB = c.NB;
+  const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
+  for (int j = J; j < JE; j += GB) {
+    const int T0 = (j + GB) / 16, TE = JE / 16;
+    long long tiles = 0;  // tiles of the super-panel's remaining columns, all rows below
+    for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
+    if (j + GB < JE && tiles <= c.cols_fused_max) {
+      // trsm + update in one kernel (every wave forms the X pieces of its tile itself: 40 MFMAs
+      // per tile instead of 8, which pays while the step has few tiles -- per LM iteration
+      // n = 3600: 2.17 against 2.36 ms, 6000: 4.72 / 4.78, 12 000 (all steps): 19.0 / 17.9)
+      hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nT, 0,
+                         TE, linv, h->status);
+      continue;
     }
-    if (JE < n32) {
-      const int Tw = JE / 16;
-      if (getenv("PSBA_CHOL_WIDE2") || (JE - J) % (2 * GB)) {  // the 2x2-tile kernel (any width; for comparison)
-        const long long MR = (nT - 1 - Tw) / 2;
-        const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
-        hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
-                           JE - J, nT, Tw, linv, h->status);
-      } else {
-        const long long MR = (nT - 1 - Tw + 3) / 4;
-        const unsigned grid = 1 + (unsigned)((MR * (MR + 1) / 2 + (nT - 1 - Tw) + 3) / 4);  // diag; 64x64 blocks, e_a tiles
-        hipLaunchKernelGGL(k_cholg_update_wide4, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, J,
-                           JE - J, nT, Tw, linv, h->status);
-      }
+    hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
+    if (j + GB < JE)
+      hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
+                         nT, TE, linv, h->status);
+  }
+  if (JE < n32) {
+    const int Tw = JE / 16;
+    if ((getenv("PSBA_CHOL_WIDE2") || (JE - J) % (2 * GB)) && nranks == 1) {  // the 2x2-tile kernel (any width; for comparison)
+      const long long MR = (nT - 1 - Tw) / 2;
+      const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
+      hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
+                         JE - J, nT, Tw, linv, h->status);
+    } else {
+      const long long MR = (nT - 1 - Tw + 3) / 4;
+      const unsigned grid = 1 + (unsigned)((MR * (MR + 1) / 2 + (nT - 1 - Tw) + 3) / 4);  // diag; 64x64 blocks, e_a tiles
+      hipLaunchKernelGGL(k_cholg_update_wide4, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, J, JE - J, nT, Tw, linv,
+                         h->status, nranks, rank);
     }
   }
+}
+
+// the backward solve of the unfused chains
+static void enqueue_backward(psba_ctx *h, hipStream_t s) {
+  const int n32 = h->n32, ld = h->n32;
+  double *Lx = h->chol_L, *linv = h->chol_ws;
+  if (!getenv("PSBA_CHOL_BACK_ONE_WG")) {
+    // one small kernel per block, all CUs (see k_cholg_back_panel); against one workgroup walking
+    // the factor (k_cholg_backward, kept for comparison): n = 780 356 / 385 us per solve, 1542
+    // 760 / 1071, 2040 1071 / 1695
+    if (getenv("PSBA_CHOL_BACK_SINGLE")) {  // one block per launch (kept for comparison)
+      for (int j = n32 - GB; j >= 0; j -= GB)
+        hipLaunchKernelGGL(k_cholg_back_panel, dim3(j / 256 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j, h->dp,
+                           linv, h->status);
+    } else {
+      for (int R = n32 / GB; R > 0;) {
+        const int nb = R < BACK_NB ? R : BACK_NB, j0 = (R - nb) * GB;
+        hipLaunchKernelGGL(k_cholg_back_multi, dim3(j0 / 64 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j0, nb,
+                           h->dp, linv, h->status);
+        R -= nb;
+      }
+    }
+  } else {
+    int thr = (n32 + 63) / 64 * 64;
+    if (thr > 512) thr = 512;
+    hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv, h->status);
+  }
+}
+
+// ---- the sharded factorization's column exchange ----
+// the 64-column block mc of the square to the right of the super-panel that ends at column JE: rows
+// from its own diagonal to the e_a row (row n32), packed row by row
+__global__ __launch_bounds__(256) void k_cholg_cols(double *Lw, int ld, int row0, int nrows, int col0, int ncols, double *buf,
+                                                    int set) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)nrows * ncols) return;
+  const int r = (int)(t / ncols), cc = (int)(t % ncols);
+  double *at = Lw + (size_t)(row0 + r) * ld + col0 + cc;
+  if (set)
+    *at = buf[t];
+  else
+    buf[t] = *at;
+}
+
+static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
+  const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;  // tile rows incl. the e_a tile
+  double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
+  // fused panel kernel (with the identity rows riding along) while a panel's tiles (one wave
+  // each, 5x the MFMA work) still fit on the chip's 1024 SIMDs at once; beyond that the
+  // redundant work is no longer free: two kernels per panel and a sequential backward solve
+  const ChainShape c = chain_shape(h);
+  const bool fused = c.fused, blocked = c.blocked, fused2 = c.fused2;
+  if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
+    hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
+  for (int J = 0; blocked && J < n32; J += c.NB) enqueue_superpanel(h, s, c, J, 1, 0);
   for (int j = 0; !blocked && j < n32; j += GB) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;
@@ -928,32 +1002,104 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
       hipLaunchKernelGGL(k_cholg_solve<16>, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,
                          linv, h->status);
   } else {
-    if (!getenv("PSBA_CHOL_BACK_ONE_WG")) {
-      // one small kernel per block, all CUs (see k_cholg_back_panel); against one workgroup walking
-      // the factor (k_cholg_backward, kept for comparison): n = 780 356 / 385 us per solve, 1542
-      // 760 / 1071, 2040 1071 / 1695
-      if (getenv("PSBA_CHOL_BACK_SINGLE")) {  // one block per launch (kept for comparison)
-        for (int j = n32 - GB; j >= 0; j -= GB)
-          hipLaunchKernelGGL(k_cholg_back_panel, dim3(j / 256 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j, h->dp,
-                             linv, h->status);
-      } else {
-        for (int R = n32 / GB; R > 0;) {
-          const int nb = R < BACK_NB ? R : BACK_NB, j0 = (R - nb) * GB;
-          hipLaunchKernelGGL(k_cholg_back_multi, dim3(j0 / 64 + 1), dim3(256), 0, s, Lx, ld, h->d.nA, n32, j0, nb,
-                             h->dp, linv, h->status);
-          R -= nb;
-        }
-      }
-    } else {
-      int thr = (n32 + 63) / 64 * 64;
-      if (thr > 512) thr = 512;
-      hipLaunchKernelGGL(k_cholg_backward, dim3(1), dim3(thr), 0, s, Lx, ld, h->d.nA, n32, h->dp, linv,
-                         h->status);
-    }
+    enqueue_backward(h, s);
   }
 }
 
+// ---- the sharded factorization (large matrices, two-level chain) ----
+// Every rank holds the complete S (all-reduce) and factors the super-panels itself; what is shared is
+// the bulk of the flops, the K = NB update of everything to the right of a super-panel: a rank
+// updates the 64-column blocks it owns (absolute block B, owner B % nranks), and before a super-panel
+// is factored the owners of its blocks send them -- rows from the block's diagonal to the e_a row --
+// to everybody.  Per super-panel of NB columns at column JE that is NB / 64 messages of
+// 8 x 64 x (n32 + 1 - 64 B) bytes (cfg5, NB = 384: six blocks, at most 6.1 MB each; 0.58 GB in all,
+// the lower triangle once); the 32-column steps inside a super-panel stay replicated.
+// The pieces are exposed one by one (psba_chol_dist_*) so that a host with its own transport -- or
+// a test with several handles on one GPU -- can drive them; with a communicator launch_chol_graph
+// runs the same sequence with ncclBroadcast.
+int chol_dist_shape(psba_ctx *h, int *NB, int *blocked) {
+  const ChainShape c = chain_shape(h);
+  *NB = c.NB;
+  *blocked = c.blocked && c.NB % 64 == 0;
+  return PSBA_OK;
+}
+
+int chol_dist_begin(psba_ctx *h) {  // the first diagonal block
+  if (!h->diag_done)
+    hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, h->stream, h->red, h->chol_L, h->n32, 0, h->chol_ws, h->status,
+                       h->chol_tim);
+  h->diag_done = false;
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+int chol_dist_superpanel(psba_ctx *h, int J) {  // its 32-column steps and this rank's share of the update
+  const ChainShape c = chain_shape(h);
+  if (J > 0)  // (its columns have just been completed by the exchange)
+    hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, h->stream, h->red, h->chol_L, h->n32, J, h->chol_ws, h->status,
+                       h->chol_tim);
+  enqueue_superpanel(h, h->stream, c, J, h->nranks, h->rank);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+// block B (columns [64 B, 64 B + 64)): rows 64 B .. n32 (the e_a row) to / from a packed device buffer
+int chol_dist_block(psba_ctx *h, int B, double *buf_dev, int set) {
+  const int row0 = 64 * B, nrows = h->n32 + 1 - row0, ncols = h->n32 - row0 < 64 ? h->n32 - row0 : 64;
+  const long long n = (long long)nrows * ncols;
+  hipLaunchKernelGGL(k_cholg_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->red, h->n32, row0, nrows,
+                     64 * B, ncols, buf_dev, set);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+int chol_dist_finish(psba_ctx *h) {
+  enqueue_backward(h, h->stream);
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+static int chol_dist_comm(psba_ctx *h) {
+  const ChainShape c = chain_shape(h);
+  const int n32 = h->n32;
+  if (!h->dist_buf) {
+    const size_t per = (size_t)(n32 + 1) * 64;
+    if (hipMalloc((void **)&h->dist_buf, sizeof(double) * per * (size_t)(c.NB / 64 + 1)) != hipSuccess)
+      return fail(h, PSBA_E_HIP, "no memory for the column exchange buffers");
+  }
+  int rc = chol_dist_begin(h);
+  for (int J = 0; J < n32 && rc == PSBA_OK; J += c.NB) {
+    rc = chol_dist_superpanel(h, J);
+    const int JE = J + c.NB;
+    if (JE >= n32 || rc != PSBA_OK) break;
+    const int B0 = JE / 64, B1 = ((JE + c.NB < n32 ? JE + c.NB : n32) + 63) / 64;  // (n32 % 64 == 32: the last block is half a block)
+    const size_t per = (size_t)(n32 + 1) * 64;
+    for (int B = B0; B < B1; B++)
+      if (B % h->nranks == h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 0);
+    if (ncclGroupStart() != ncclSuccess) return fail(h, PSBA_E_RCCL, "ncclGroupStart failed");
+    for (int B = B0; B < B1; B++) {
+      double *b = h->dist_buf + (size_t)(B - B0) * per;
+      const size_t n = (size_t)(n32 + 1 - 64 * B) * (size_t)(n32 - 64 * B < 64 ? n32 - 64 * B : 64);
+      if (ncclBroadcast(b, b, n, ncclDouble, B % h->nranks, h->comm, h->stream) != ncclSuccess)
+        return fail(h, PSBA_E_RCCL, "ncclBroadcast failed in the column exchange");
+    }
+    if (ncclGroupEnd() != ncclSuccess) return fail(h, PSBA_E_RCCL, "ncclGroupEnd failed");
+    for (int B = B0; B < B1 && rc == PSBA_OK; B++)
+      if (B % h->nranks != h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 1);
+  }
+  if (rc == PSBA_OK) rc = chol_dist_finish(h);
+  return rc;
+}
+
 int launch_chol_graph(psba_ctx *h) {
+  if (h->comm && h->nranks > 1 && !getenv("PSBA_CHOL_REPLICATED")) {
+    int NB, blocked;
+    chol_dist_shape(h, &NB, &blocked);
+    if (blocked) {
+      ProfScope ps(h, PSBA_K_CHOLESKY);
+      return chol_dist_comm(h);
+    }
+  }
   const int v = h->diag_done ? 1 : 0;
   h->diag_done = false;
   // The chain is enqueued directly.  Replaying it as a captured hipGraph (PSBA_CHOL_GRAPH=1; the

@@ -158,6 +158,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->trv[1]);
   dev_free(h->jmul_out);
   dev_free(h->chol_ws);
+  dev_free(h->dist_buf);
   dev_free(h->chol_L);
   dev_free(h->dbg_ex);
   dev_free(h->dbg_JA);
@@ -773,6 +774,57 @@ int psba_accept(psba_handle h) {
 // ---- operators of the trust-region caller ---------------------------------
 
 static int d2h(psba_ctx *h, void *dst, const void *src, size_t bytes);
+
+// ---- the sharded dense factorization, piece by piece (kernels_chol_graph.hip: chol_dist_*) ----
+int psba_chol_dist_shape(psba_handle h, int *n32, int *NB, int *sharded) {
+  CHECK_H(h);
+  NEED(h, h->uploaded, "no problem uploaded");
+  int nb = 0, bl = 0;
+  TRY(chol_dist_shape(h, &nb, &bl));
+  if (n32) *n32 = h->n32;
+  if (NB) *NB = nb;
+  if (sharded) *sharded = bl;
+  return PSBA_OK;
+}
+int psba_chol_dist_begin(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble (and the reduction over ranks) first");
+  if (h->packed_pending) {
+    TRY(launch_schur_expand(h));
+    h->packed_pending = false;
+  }
+  return chol_dist_begin(h);
+}
+int psba_chol_dist_superpanel(psba_handle h, int J) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  if (J < 0 || J >= h->n32) return fail(h, PSBA_E_INVALID, "super-panel column %d out of range", J);
+  return chol_dist_superpanel(h, J);
+}
+int psba_chol_dist_block(psba_handle h, int B, int set, double *buf, long long *n_doubles) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  if (B < 0 || 64 * B >= h->n32) return fail(h, PSBA_E_INVALID, "column block %d out of range", B);
+  const int ncols = h->n32 - 64 * B < 64 ? h->n32 - 64 * B : 64;
+  const long long n = (long long)(h->n32 + 1 - 64 * B) * ncols;
+  if (n_doubles) *n_doubles = n;
+  if (!buf) return PSBA_OK;
+  if (!h->dist_buf) TRY(dev_alloc(h, &h->dist_buf, (size_t)(h->n32 + 1) * 64 * 8));
+  if (set) {
+    PSBA_HIP(h, hipMemcpyAsync(h->dist_buf, buf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    return chol_dist_block(h, B, h->dist_buf, 1);
+  }
+  TRY(chol_dist_block(h, B, h->dist_buf, 0));
+  return d2h(h, buf, h->dist_buf, sizeof(double) * (size_t)n);
+}
+int psba_chol_dist_finish(psba_handle h) {
+  CHECK_H(h);
+  NEED(h, h->assembled, "psba_schur_assemble first");
+  TRY(chol_dist_finish(h));
+  h->assembled = false;
+  h->solved = true;
+  return PSBA_OK;
+}
 
 static int ensure_trv(psba_ctx *h) {
   for (int k = 0; k < 2; k++)

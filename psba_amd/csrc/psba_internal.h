@@ -232,6 +232,7 @@ struct psba_ctx {
   double *chol_graph_red[2] = {nullptr, nullptr};
   long long *chol_tim = nullptr; // dev instrumentation: per-phase s_memtime ticks of the last solve (PSBA_CHOL_TIMING)
   double *chol_L = nullptr;     // [(2 n32+16)][n32] panel chain: the Cholesky factor | forward-solved e_a row | L^-T
+  double *dist_buf = nullptr;   // sharded factorization: packed column blocks of one super-panel (allocated on first use)
   double *chol_ws = nullptr;    // [ceil(nA/32)][32*32] inverses of the diagonal blocks of L (diagBlkAux_buffer)
   double *scal = nullptr;       // [NSCAL]
   // [4] generation stamps, never zeroed: [0] == try_id <=> some V_i singular in this try,
@@ -303,6 +304,11 @@ int launch_schur_expand(psba_ctx *h);
 int launch_chol_solve(psba_ctx *h);
 // kernels_chol_graph.hip
 int launch_chol_graph(psba_ctx *h);
+int chol_dist_shape(psba_ctx *h, int *NB, int *blocked);
+int chol_dist_begin(psba_ctx *h);
+int chol_dist_superpanel(psba_ctx *h, int J);
+int chol_dist_block(psba_ctx *h, int B, double *buf_dev, int set);
+int chol_dist_finish(psba_ctx *h);
 // kernels_backsub.hip
 int launch_backsub(psba_ctx *h, double mu, bool dump);
 int launch_publish_scal(psba_ctx *h, hipStream_t s);

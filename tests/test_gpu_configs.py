@@ -364,6 +364,63 @@ def test_owner_route_beyond_the_lds_limit_of_the_atomic_kernel():
     h.close()
 
 
+def test_sharded_dense_factorization_emulated_with_three_handles():
+    """BASELINE configs[4] runs on 8 GPUs and its dense 12 000 x 12 000 factorization is 60 % of an LM
+    iteration: replicated on every rank it would cap the scaling at 1.6x.  The two-level chain can
+    be sharded instead (include/psba_hip.h, psba_chol_dist_*): super-panels factored by everybody,
+    the K = NB update of everything to their right split over the ranks by 64-column block, the
+    owners sending a super-panel's blocks to everybody before it is factored.  Three handles on one
+    GPU with a rank layout of three take the same complete S and exchange the blocks by hand: every
+    one of them must arrive at the single-handle solution.  (With a communicator psba_schur_solve
+    runs the same sequence over ncclBroadcast: no multi-GPU hardware here -- unmeasured.)"""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=340, n_pts=3000, mean_track=5.0, seed=340)
+    ref = psba_amd.Psba(0)
+    ref.upload_problem(prob)
+    ref.linearize(1.0, 1.0)
+    mu = 1e-3 * ref.max_diag()
+    ref.schur_assemble(mu)
+    Sbuf = ref.get_reduce_buffer()
+    n32, NB, sharded = ref.chol_dist_shape()
+    assert sharded and n32 == 2048 and NB % 64 == 0
+    ref.schur_reduce()
+    ref.schur_solve()
+    nA = 6 * 340
+    want = ref.get_dp()[:nA]
+    ref.close()
+    hs = []
+    for r in range(3):
+        h = psba_amd.Psba(0)
+        h.set_rank_layout(3, r)
+        h.upload_problem(prob)
+        h.linearize(1.0, 1.0)
+        h.schur_assemble(mu)
+        h.set_reduce_buffer(Sbuf)  # the complete S, as after the all-reduce
+        h.chol_dist_begin()
+        hs.append(h)
+    moved = 0
+    for J in range(0, n32, NB):
+        for h in hs:
+            h.chol_dist_superpanel(J)
+        JE = J + NB
+        if JE >= n32:
+            break
+        for B in range(JE // 64, (min(JE + NB, n32) + 63) // 64):
+            buf = hs[B % 3].chol_dist_get_block(B)
+            assert buf.size == (n32 + 1 - 64 * B) * min(64, n32 - 64 * B)
+            moved += buf.size
+            for r, h in enumerate(hs):
+                if r != B % 3:
+                    h.chol_dist_set_block(B, buf)
+    assert moved > 0
+    for h in hs:
+        h.chol_dist_finish()
+        got = h.get_dp()[:nA]
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+        h.close()
+
+
 def test_points_seen_by_more_cameras_than_a_tile_holds():
     """The reference puts no limit on how many cameras see a point (CL_files/compute_V.cl:6-38,
     compute_eb.cl:28-37 loop over all of them).  The tile kernels hold 256 observations per tile;
