@@ -90,7 +90,8 @@ int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
  * this rank), 1 = the owner route for larger problems (one thread per block segment,
  * products sorted by camera pair, sums in registers; PSBA_SCHUR_OWNER=1 forces it), 2 = global
  * fp64 atomics straight into S (the
- * first-generation kernel, kept for cross-checks: PSBA_SCHUR_ATOMIC=1).  The reference has one
+ * first-generation kernel, kept for cross-checks: PSBA_SCHUR_ATOMIC=1), 3 = the ring route (opt-in
+ * experiment, PSBA_SCHUR_RING=1), 4 = block-sparse S (PSBA_SOLVER_PCG).  The reference has one
  * route for every size (CL_files/compute_S.cl:6-78). */
 int psba_schur_path(psba_handle h, int *path);
 
@@ -326,6 +327,23 @@ int psba_profile_get(psba_handle h, int kernel, double *total_ms, int *launches)
 /* algorithmic bytes of one launch of a kernel class for the uploaded problem
  * (SURVEY.md section 8(d) formulas; stated in DESIGN.md) */
 int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
+
+/* ---- block-sparse S and an iterative solve -----------------------------------------
+ * The reference forms the dense nA x nA S for every problem (CL_files/compute_S.cl:6-78) and inverts it
+ * (PSBA/cl_spdinv.cpp:18-40).  With PSBA_SOLVER_PCG only the 6x6 blocks of camera pairs that see a
+ * common point exist (the lower block triangle as a list; no dense buffer is allocated), and
+ * psba_schur_solve runs conjugate gradients with a block-Jacobi preconditioner until
+ * ||S x - e_a|| <= tol ||e_a|| or max_iter iterations; a diagonal block that is not positive definite or
+ * a direction of non-positive curvature reports PSBA_NOT_SPD, so psba_levmar works unchanged.  The
+ * sba_func.h mirror verbs and the trust-region operators need the dense S and refuse this mode.
+ * psba_set_solver: before psba_upload_problem; tol <= 0 / max_iter <= 0 keep 1e-10 / 500. */
+#define PSBA_SOLVER_DENSE 0
+#define PSBA_SOLVER_PCG 1
+int psba_set_solver(psba_handle h, int solver, double tol, int max_iter);
+/* iterations and ||r|| / ||e_a|| of the last solve; blocks stored / blocks of the dense lower triangle */
+int psba_pcg_info(psba_handle h, int *iters, double *relres, long long *blocks, long long *dense_blocks);
+/* the assembled blocks: jk[2 blocks] = (j, k), k <= j; val[36 blocks] row-major; ea[nA]; any pointer may be NULL */
+int psba_get_sparse_S(psba_handle h, int *jk, double *val, double *ea);
 
 /* ---- the dense factorization sharded over ranks (large matrices: the two-level chain) --------------
  * The reference factors S on one device (PSBA/cl_spdinv.cpp:18-40, CL_files/SPD_inv.cl:165-179).

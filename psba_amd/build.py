@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpsba_hip.so")
 SOURCES = ["psba_api.cpp", "schur_plan.cpp", "lm_loop.cpp", "tr_loop.cpp", "sba_io.cpp", "kernels_linearize.hip",
            "kernels_tr.hip",
-           "kernels_schur.hip", "kernels_schur_ring.hip", "schur_ring_plan.cpp", "kernels_chol.hip", "kernels_chol_graph.hip", "kernels_backsub.hip"]
+           "kernels_schur.hip", "kernels_schur_ring.hip", "schur_ring_plan.cpp", "kernels_chol.hip", "kernels_pcg.hip", "kernels_chol_graph.hip", "kernels_backsub.hip"]
 HEADERS = ["psba_internal.h", "camera_model.h", "chol_factor32.h", "schur_common.h", os.path.join("..", "..", "include", "psba_hip.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

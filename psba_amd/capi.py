@@ -133,6 +133,9 @@ SIGNATURES = [
     ("psba_write_problem", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]),
     ("psba_convert_bal", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dp]),
     ("psba_allreduce_scalars", C.c_int, [_h, _dp, C.c_int]),
+    ("psba_set_solver", C.c_int, [_h, C.c_int, C.c_double, C.c_int]),
+    ("psba_pcg_info", C.c_int, [_h, _ip, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    ("psba_get_sparse_S", C.c_int, [_h, _ip, _dp, _dp]),
     ("psba_chol_dist_shape", C.c_int, [_h, _ip, _ip, _ip]),
     ("psba_chol_dist_begin", C.c_int, [_h]),
     ("psba_chol_dist_superpanel", C.c_int, [_h, C.c_int]),
@@ -468,6 +471,24 @@ class Psba:
         log = np.zeros((max(log_cap, 1), 5))
         self._ck(lib.psba_levmar(self._h, C.byref(opts), C.byref(res), _d(log)))
         return res, log[: res.n_log].copy()
+
+    # ---- block-sparse S + PCG ----
+    def set_solver(self, solver, tol=0.0, max_iter=0):
+        """solver: 0 dense Cholesky, 1 block-sparse S + preconditioned CG (before upload_problem)."""
+        self._ck(lib.psba_set_solver(self._h, int(solver), float(tol), int(max_iter)))
+
+    def pcg_info(self):
+        it, rr, nb, nd = C.c_int(), C.c_double(), C.c_longlong(), C.c_longlong()
+        self._ck(lib.psba_pcg_info(self._h, C.byref(it), C.byref(rr), C.byref(nb), C.byref(nd)))
+        return it.value, rr.value, nb.value, nd.value
+
+    def get_sparse_S(self):
+        nb = self.pcg_info()[2]
+        jk = np.empty((nb, 2), dtype=np.int32)
+        val = np.empty((nb, 6, 6))
+        ea = np.empty(6 * self.nC)
+        self._ck(lib.psba_get_sparse_S(self._h, _i(jk), _d(val), _d(ea)))
+        return jk, val, ea
 
     # ---- the sharded dense factorization, piece by piece ----
     def chol_dist_shape(self):

@@ -518,6 +518,7 @@ struct SchurOwnerArgs {
   int *status;
   double mu;
   int nWaves, ld, try_id;
+  int bsr;  // 1: S is the block-sparse list (36 doubles per block, unit.slot), e_a a vector of its own
 };
 
 __global__ __launch_bounds__(256) void k_schur_owner(SchurOwnerArgs p) {
@@ -577,18 +578,19 @@ __global__ __launch_bounds__(256) void k_schur_owner(SchurOwnerArgs p) {
     }
     ab = nxt;
   }
-  if (un.pad) return;  // idle lane of the last wave
-  double *Sb = p.S + (size_t)(6 * un.j) * p.ld + 6 * un.k;
+  if (un.slot < 0) return;  // idle lane of the last wave
+  const int ldb = p.bsr ? 6 : p.ld;
+  double *Sb = p.bsr ? p.S + 36 * (size_t)un.slot : p.S + (size_t)(6 * un.j) * p.ld + 6 * un.k;
   if (un.multi) {
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
-      for (int c = 0; c < 6; c++) atomicAdd(&Sb[(size_t)r * p.ld + c], acc[6 * r + c]);
+      for (int c = 0; c < 6; c++) atomicAdd(&Sb[(size_t)r * ldb + c], acc[6 * r + c]);
   } else {
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
-      for (int c = 0; c < 6; c++) Sb[(size_t)r * p.ld + c] = acc[6 * r + c];
+      for (int c = 0; c < 6; c++) Sb[(size_t)r * ldb + c] = acc[6 * r + c];
   }
   if (diag) {
 #pragma unroll
@@ -699,10 +701,50 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
   return PSBA_OK;
 }
 
+// block-sparse mode (psba_set_solver PSBA_SOLVER_PCG): the owner route writes the blocks that exist,
+// nothing dense is allocated; k_bsr_finalize adds U + mu I and g_a
+static int launch_schur_sparse(psba_ctx *h, double mu) {
+  PSBA_HIP(h, hipMemsetAsync(h->bs_val, 0, sizeof(double) * ((size_t)36 * h->bs_nblk + h->d.nA), h->stream));
+  SchurOwnerArgs o;
+  o.W = h->W;
+  o.PV = h->PV;
+  o.iidx = h->iidx;
+  o.prod = h->own_prod;
+  o.waves = h->own_waves;
+  o.units = h->own_units;
+  o.S = h->bs_val;
+  o.ea = h->bs_ea;
+  o.status = h->status;
+  o.mu = mu;
+  o.nWaves = h->own_nwaves;
+  o.ld = 6;
+  o.try_id = h->try_id;
+  o.bsr = 1;
+  const bool pair = (h->prof & (1u << PSBA_K_SCHUR)) && !(h->prof & (1u << PSBA_K_SCHUR_REDUCE));
+  {
+    ProfScope pp(h, pair ? PSBA_K_SCHUR : -1);
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR);
+      hipLaunchKernelGGL(k_schur_owner, dim3((h->own_nwaves + 3) / 4), dim3(256), 0, h->stream, o);
+    }
+    {
+      ProfScope ps(h, pair ? -1 : PSBA_K_SCHUR_REDUCE);
+      const int rc = launch_bsr_finalize(h, mu);
+      if (rc != PSBA_OK) return rc;
+    }
+  }
+  PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
 int launch_schur(psba_ctx *h, double mu, bool dump) {
   h->try_id++;
   h->diag_done = false;
   h->packed_pending = false;  // status words are generation stamps: nothing to zero
+  if (h->solver == PSBA_SOLVER_PCG) {
+    if (dump) return fail(h, PSBA_E_INVALID, "the sba_func.h mirror verbs need the dense S: PSBA_SOLVER_DENSE");
+    return launch_schur_sparse(h, mu);
+  }
   if (h->ring_nWg > 0 && !getenv("PSBA_SCHUR_ATOMIC")) return launch_schur_ring(h, mu, dump);
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
     if (!h->lds_attr_set) {
@@ -777,6 +819,7 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
         o.nWaves = h->own_nwaves;
         o.ld = h->n32;
         o.try_id = h->try_id;
+        o.bsr = 0;
         hipLaunchKernelGGL(k_schur_owner, dim3((h->own_nwaves + 3) / 4), dim3(256), 0, h->stream, o);
       } else {
         if (dump)

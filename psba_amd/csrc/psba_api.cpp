@@ -149,6 +149,14 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->ring_slab);
   dev_free(h->ring_pvi);
   h->ring_nWg = h->ring_nS = 0;
+  dev_free(h->bs_val);
+  h->bs_ea = nullptr;
+  dev_free(h->bs_jk);
+  dev_free(h->bs_diag);
+  dev_free(h->pcg_vec);
+  dev_free(h->pcg_minv);
+  dev_free(h->pcg_scal);
+  h->bs_nblk = 0;
   dev_free(h->own_prod);
   dev_free(h->own_waves);
   dev_free(h->own_units);
@@ -216,6 +224,7 @@ int psba_destroy(psba_handle h) {
   free_problem_buffers(h);
   dev_free(h->scal);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->pcg_host) (void)hipHostFree(h->pcg_host);
   if (h->scal_event) (void)hipEventDestroy(h->scal_event);
   for (auto &s : h->spans) {
     (void)hipEventDestroy(s.a);
@@ -229,7 +238,7 @@ int psba_destroy(psba_handle h) {
 int psba_schur_path(psba_handle h, int *path) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
-  if (path) *path = getenv("PSBA_SCHUR_ATOMIC") ? 2 : h->ring_nWg > 0 ? 3 : h->nGroups > 0 ? 0 : 1;
+  if (path) *path = h->solver == PSBA_SOLVER_PCG ? 4 : getenv("PSBA_SCHUR_ATOMIC") ? 2 : h->ring_nWg > 0 ? 3 : h->nGroups > 0 ? 0 : 1;
   return PSBA_OK;
 }
 
@@ -366,15 +375,48 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   h->n32 = (d.nA + 31) / 32 * 32;
   // rows [0, n32 + 16) are the reduce buffer proper; n32 more rows below it are the working
   // space of the identity rows the panel chain carries along (kernels_chol_graph.hip)
-  TRY(dev_alloc(h, &h->red, (size_t)(2 * h->n32 + 16) * h->n32));
-  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(2 * h->n32 + 16) * h->n32, h->stream));
+  const bool sparse = h->solver == PSBA_SOLVER_PCG;  // no dense S, no factor: only the blocks that exist (below)
+  const size_t dense = sparse ? 1 : (size_t)(2 * h->n32 + 16) * h->n32;
+  TRY(dev_alloc(h, &h->red, dense));
+  PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * dense, h->stream));
   TRY(dev_alloc(h, &h->dp, (size_t)(d.nT > 36 * d.nC ? d.nT : 36 * d.nC)));
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
-  TRY(dev_alloc(h, &h->chol_L, (size_t)(2 * h->n32 + 16) * h->n32));
-  PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * (size_t)(2 * h->n32 + 16) * h->n32, h->stream));
+  TRY(dev_alloc(h, &h->chol_L, dense));
+  PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * dense, h->stream));
   if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
   // ---- K2's static schedule (groups of blocks, workgroups, conflict-free item rows) ----
-  {
+  if (sparse) {
+    // block-sparse S: the owner route's product lists give the blocks that exist
+    OwnerPlanHost op;
+    TRY(build_owner_plan(nCams, n2Dprojs, iidx, jidx, ptr.data(), op));
+    h->nGroups = 0;
+    h->packedN = 36 * (size_t)nCams * (nCams + 1) / 2;
+    TRY(dev_alloc(h, &h->own_prod, op.prod.size()));
+    TRY(dev_alloc(h, &h->own_waves, op.waves.size()));
+    TRY(dev_alloc(h, &h->own_units, op.units.size()));
+    PSBA_HIP(h, hipMemcpy(h->own_prod, op.prod.data(), sizeof(int2) * op.prod.size(), hipMemcpyHostToDevice));
+    PSBA_HIP(h, hipMemcpy(h->own_waves, op.waves.data(), sizeof(OwnerWave) * op.waves.size(), hipMemcpyHostToDevice));
+    PSBA_HIP(h, hipMemcpy(h->own_units, op.units.data(), sizeof(OwnerUnit) * op.units.size(), hipMemcpyHostToDevice));
+    h->own_nwaves = (int)op.waves.size();
+    h->own_products = op.products;
+    h->bs_nblk = (long long)op.blocks.size();
+    TRY(dev_alloc(h, &h->bs_val, (size_t)36 * op.blocks.size() + (size_t)d.nA));
+    h->bs_ea = h->bs_val + (size_t)36 * op.blocks.size();
+    TRY(dev_alloc(h, &h->bs_jk, op.blocks.size()));
+    TRY(dev_alloc(h, &h->bs_diag, op.diag_slot.size()));
+    PSBA_HIP(h, hipMemcpy(h->bs_jk, op.blocks.data(), sizeof(int2) * op.blocks.size(), hipMemcpyHostToDevice));
+    PSBA_HIP(h, hipMemcpy(h->bs_diag, op.diag_slot.data(), sizeof(int) * op.diag_slot.size(), hipMemcpyHostToDevice));
+    TRY(dev_alloc(h, &h->pcg_vec, (size_t)4 * d.nA));
+    TRY(dev_alloc(h, &h->pcg_minv, (size_t)36 * d.nC));
+    TRY(dev_alloc(h, &h->pcg_scal, (size_t)8));
+    if (!h->pcg_host && hipHostMalloc((void **)&h->pcg_host, sizeof(double) * 8) != hipSuccess)
+      return fail(h, PSBA_E_NOMEM, "no pinned memory for the PCG scalars");
+    if (getenv("PSBA_SCHUR_PLAN_INFO"))
+      fprintf(stderr, "[psba] block-sparse S: %lld of %lld blocks of the lower block triangle (%.1f %%), %lld products\n",
+              h->bs_nblk, (long long)nCams * (nCams + 1) / 2, 100.0 * (double)h->bs_nblk / ((double)nCams * (nCams + 1) / 2),
+              op.products);
+  }
+  if (!sparse) {
     RingPlanHost rp;
     TRY(build_ring_plan(nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), rp));
     if (rp.nWg > 0) {
@@ -416,7 +458,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       }
     }
   }
-  if (!h->ring_nWg) {
+  if (!sparse && !h->ring_nWg) {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
     if (h->nGroups) {
@@ -637,6 +679,11 @@ int psba_schur_assemble(psba_handle h, double mu) {
 // (about half the bytes of the padded square), then scattered into the padded buffer; the whole
 // padded square for the global-atomic fallback kernel
 static int allreduce_schur(psba_ctx *h) {
+  if (h->solver == PSBA_SOLVER_PCG) {  // the blocks that exist and e_a behind them: one collective
+    if (h->comm)
+      RCCL(h, ncclAllReduce(h->bs_val, h->bs_val, (size_t)36 * h->bs_nblk + h->d.nA, ncclDouble, ncclSum, h->comm, h->stream));
+    return PSBA_OK;
+  }
   if (h->packed_pending) {
     if (h->comm)
       RCCL(h, ncclAllReduce(h->redp, h->redp, h->packed_doubles, ncclDouble, ncclSum, h->comm, h->stream));
@@ -662,6 +709,12 @@ int psba_schur_solve(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
   if (h->packed_pending) TRY(allreduce_schur(h));  // psba_schur_reduce was skipped
+  if (h->solver == PSBA_SOLVER_PCG) {
+    TRY(launch_pcg_solve(h));
+    h->assembled = false;
+    h->solved = true;
+    return PSBA_OK;
+  }
   TRY(launch_chol_solve(h));
   if (h->chol_tim) {
     long long t[16];
@@ -850,6 +903,36 @@ int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dot
   return PSBA_OK;
 }
 
+int psba_set_solver(psba_handle h, int solver, double tol, int max_iter) {
+  CHECK_H(h);
+  if (solver != PSBA_SOLVER_DENSE && solver != PSBA_SOLVER_PCG) return fail(h, PSBA_E_INVALID, "unknown solver %d", solver);
+  NEED(h, !h->uploaded || solver == h->solver, "psba_set_solver before psba_upload_problem (the buffers depend on it)");
+  h->solver = solver;
+  if (tol > 0) h->pcg_tol = tol;
+  if (max_iter > 0) h->pcg_maxit = max_iter;
+  return PSBA_OK;
+}
+
+int psba_pcg_info(psba_handle h, int *iters, double *relres, long long *blocks, long long *dense_blocks) {
+  CHECK_H(h);
+  NEED(h, h->uploaded && h->solver == PSBA_SOLVER_PCG, "PSBA_SOLVER_PCG and an uploaded problem");
+  if (iters) *iters = h->pcg_iters;
+  if (relres) *relres = h->pcg_relres;
+  if (blocks) *blocks = h->bs_nblk;
+  if (dense_blocks) *dense_blocks = (long long)h->d.nC * (h->d.nC + 1) / 2;
+  return PSBA_OK;
+}
+
+// the block-sparse S as assembled (after psba_schur_assemble / psba_schur_reduce): jk[2 blocks], val[36 blocks], ea[nA]
+int psba_get_sparse_S(psba_handle h, int *jk, double *val, double *ea) {
+  CHECK_H(h);
+  NEED(h, h->assembled && h->solver == PSBA_SOLVER_PCG, "psba_schur_assemble with PSBA_SOLVER_PCG first");
+  if (jk) TRY(d2h(h, jk, h->bs_jk, sizeof(int2) * (size_t)h->bs_nblk));
+  if (val) TRY(d2h(h, val, h->bs_val, sizeof(double) * 36 * (size_t)h->bs_nblk));
+  if (ea) TRY(d2h(h, ea, h->bs_ea, sizeof(double) * (size_t)h->d.nA));
+  return PSBA_OK;
+}
+
 int psba_allreduce_scalars(psba_handle h, double *v, int n) {
   CHECK_H(h);
   if (!v || n < 0 || n > 8) return fail(h, PSBA_E_INVALID, "psba_allreduce_scalars: at most 8 values");
@@ -904,6 +987,7 @@ int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *i
   NEED(h, h->uploaded, "no problem uploaded");
   if (h->nranks > 1 && !h->comm)
     return fail(h, PSBA_E_INVALID, "psba_cholmod_lambda on a rank layout needs the communicator (S must be complete)");
+  NEED(h, h->solver != PSBA_SOLVER_PCG, "the modified Cholesky needs the dense S: PSBA_SOLVER_DENSE");
   if (reassemble) {
     // S at lambda = 0 again (the failed factorization worked in place), then the modified
     // Cholesky on a copy of it (trust_region.cpp:341-363)
@@ -1207,6 +1291,7 @@ int psba_get_reduce_buffer(psba_handle h, double *out) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble first");
   NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
+  NEED(h, h->solver != PSBA_SOLVER_PCG, "no dense reduce buffer with PSBA_SOLVER_PCG (psba_get_sparse_S)");
   if (packed_hook(h)) return d2h(h, out, h->redp, sizeof(double) * h->packed_doubles);
   return d2h(h, out, h->red, sizeof(double) * (size_t)(h->n32 + 1) * h->n32);
 }

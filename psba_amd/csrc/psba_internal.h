@@ -76,12 +76,14 @@ struct OwnerWave {
 struct OwnerUnit {
   int j, k;        // block (j, k), k <= j
   int multi;       // 1: the block has several units -> atomic adds into the zeroed S; 0: plain stores
-  int pad;
+  int slot;        // index of the block in the block-sparse list (psba_set_solver PSBA_SOLVER_PCG); -1: idle lane of the last wave
 };
 struct OwnerPlanHost {
   std::vector<int2> prod;          // (a, b) observation indices; a = -1: padding
   std::vector<OwnerWave> waves;
   std::vector<OwnerUnit> units;    // 64 per wave
+  std::vector<int2> blocks;        // the non-empty blocks (j, k), k <= j, plus every diagonal block: canonical order
+  std::vector<int> diag_slot;      // [nC] index of block (j, j) in `blocks`
   long long products = 0;
 };
 // ---- K2 ring route (few cameras): schur_ring_plan.cpp / kernels_schur_ring.hip ----
@@ -218,6 +220,19 @@ struct psba_ctx {
   size_t ring_loaded_recs = 0;
   bool ring_attr_set = false;
   long long *chol_tim_ring = nullptr;  // dev instrumentation (PSBA_RING_TIMING): per-step s_memtime stamps of two workgroups
+  // block-sparse S + preconditioned CG (psba_set_solver, kernels_pcg.hip)
+  int solver = 0;               // PSBA_SOLVER_*
+  double pcg_tol = 1e-10;
+  int pcg_maxit = 500, pcg_iters = 0;
+  double pcg_relres = 0.0;
+  long long bs_nblk = 0;
+  double *bs_val = nullptr;     // [bs_nblk][36] | e_a [nA] right behind (one all-reduce)
+  double *bs_ea = nullptr;      // = bs_val + 36 bs_nblk
+  int2 *bs_jk = nullptr;        // [bs_nblk] (j, k)
+  int *bs_diag = nullptr;       // [nC] index of block (j, j)
+  double *pcg_vec = nullptr;    // r | z | p | q, nA each
+  double *pcg_minv = nullptr;   // [nC][36] inverses of the diagonal blocks
+  double *pcg_scal = nullptr, *pcg_host = nullptr;  // device scalars and their pinned mirror
   // K2 owner route (many cameras): see OwnerPlanHost
   int2 *own_prod = nullptr;
   psba::OwnerWave *own_waves = nullptr;
@@ -302,6 +317,9 @@ int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip
 int launch_chol_solve(psba_ctx *h);
+// kernels_pcg.hip
+int launch_bsr_finalize(psba_ctx *h, double mu);
+int launch_pcg_solve(psba_ctx *h);
 // kernels_chol_graph.hip
 int launch_chol_graph(psba_ctx *h);
 int chol_dist_shape(psba_ctx *h, int *NB, int *blocked);

@@ -313,6 +313,19 @@ int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, cons
   long long LMAX = (total + 262143) / 262144;
   if (LMAX < 16) LMAX = 16;
   if (const char *e = getenv("PSBA_OWNER_LMAX")) LMAX = atoll(e) > 0 ? atoll(e) : LMAX;
+  // the blocks that exist: every diagonal block, and the off-diagonal ones with at least one product
+  out.blocks.clear();
+  out.diag_slot.assign((size_t)nCams, 0);
+  std::vector<int> slot_of((size_t)nBlk, -1);
+  for (int j = 0; j < nCams; j++)
+    for (int k = 0; k <= j; k++) {
+      const long long blk = tri(j) + k;
+      if (k == j || cnt[(size_t)blk + 1] > cnt[(size_t)blk]) {
+        slot_of[(size_t)blk] = (int)out.blocks.size();
+        if (k == j) out.diag_slot[(size_t)j] = (int)out.blocks.size();
+        out.blocks.push_back(make_int2(j, k));
+      }
+    }
   struct Unit { long long first; int len, j, k, multi; };
   std::vector<Unit> units;
   units.reserve((size_t)(total / LMAX + nBlk));
@@ -339,11 +352,11 @@ int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, cons
   out.prod.assign((size_t)rows * 64, make_int2(-1, -1));
   for (size_t u = 0; u < units.size(); u++) {
     const size_t w = u / 64, lane = u % 64;
-    out.units[u] = {units[u].j, units[u].k, units[u].multi, 0};
+    out.units[u] = {units[u].j, units[u].k, units[u].multi, slot_of[(size_t)(tri(units[u].j) + units[u].k)]};
     int2 *dst = out.prod.data() + (size_t)out.waves[w].row0 * 64 + lane;
     for (int t = 0; t < units[u].len; t++) dst[(size_t)t * 64] = sorted[(size_t)(units[u].first + t)];
   }
-  for (size_t u = units.size(); u < nW * 64; u++) out.units[u] = {0, 0, 1, 1};  // idle lanes (pad = 1)
+  for (size_t u = units.size(); u < nW * 64; u++) out.units[u] = {0, 0, 1, -1};  // idle lanes (slot = -1)
   out.products = total;
   return PSBA_OK;
 }

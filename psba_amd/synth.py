@@ -40,15 +40,21 @@ def project(K, q0, cams, M):
 
 
 def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, noise_px=1.0,
-                 cam_sigma=1e-3, pt_sigma=1e-2, focal=1000.0, shard=0):
+                 cam_sigma=1e-3, pt_sigma=1e-2, focal=1000.0, shard=0, window=None):
     """Cameras on a circle of radius 10 looking at the origin; points in the unit ball.
 
     `shard` selects an independent stream for the points and observations while the cameras
     (and their initial perturbation) depend on `seed` only: shards 0..N-1 of one seed are the
-    per-rank pieces of one N-times-larger problem over the same cameras."""
+    per-rank pieces of one N-times-larger problem over the same cameras.
+
+    `window`: a point's cameras are drawn from `window` neighbours on the circle (around a random
+    camera) instead of from all of them -- the co-visibility of a camera sequence: the reduced camera
+    matrix S then has non-zero blocks only within that band (and its wrap-around corner)."""
     rng = np.random.default_rng([seed, 1 + shard])
     rng_cam = np.random.default_rng([seed, 0])
     max_track = n_cams if max_track is None else min(max_track, n_cams)
+    if window is not None:
+        max_track = min(max_track, int(window))
     # cameras: centre c_j on a circle, rotation taking the world z-axis towards the origin
     ang = 2 * np.pi * np.arange(n_cams) / n_cams
     C = np.stack([10 * np.cos(ang), 10 * np.sin(ang), 0.3 * np.sin(3 * ang)], -1)
@@ -91,7 +97,12 @@ def make_problem(n_cams, n_pts, mean_track, seed, min_track=2, max_track=None, n
     off = np.concatenate([[0], np.cumsum(k)])
     for kk in np.unique(k):
         rows = np.nonzero(k == kk)[0]
-        if n_cams > 256 and 4 * kk < n_cams:
+        if window is not None:
+            keys = rng.random((rows.size, int(window)))
+            offs = np.argpartition(keys, kk - 1, axis=1)[:, :kk]
+            start = rng.integers(0, n_cams, size=(rows.size, 1))
+            pick = np.sort((start + offs) % n_cams, axis=1).astype(np.int32)
+        elif n_cams > 256 and 4 * kk < n_cams:
             # many cameras, short tracks: draw indices and redraw the few rows with repeats (the
             # dense rows x cameras key matrix below would be rows x n_cams doubles)
             pick = np.sort(rng.integers(0, n_cams, size=(rows.size, kk)), axis=1)

@@ -364,6 +364,71 @@ def test_owner_route_beyond_the_lds_limit_of_the_atomic_kernel():
     h.close()
 
 
+@pytest.mark.parametrize("n_cams,window", [(60, None), (1000, 40)])
+def test_block_sparse_S_and_pcg(n_cams, window):
+    """only the blocks of S whose cameras see a common point are stored (the reference
+    stores and inverts the dense S: CL_files/compute_S.cl:6-78, PSBA/cl_spdinv.cpp:18-40), and the
+    reduced system is solved by block-Jacobi preconditioned conjugate gradients.  1000 cameras in a
+    sequence (a point's cameras within a window of 40): the stored blocks against the dense S of the
+    default route block by block, absent blocks exactly zero there, dpa against the dense
+    factorization's at 1e-8, and the LM run through the iterative solve against the dense one."""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=n_cams, n_pts=6000, mean_track=5.0, seed=77 + n_cams, window=window)
+    ref = psba_amd.Psba(0)
+    ref.upload_problem(prob)
+    ref.linearize(1.0, 1.0)
+    mu = 1e-3 * ref.max_diag()
+    ref.schur_assemble(mu)
+    nA = 6 * n_cams
+    n32 = (nA + 31) // 32 * 32
+    M = ref.get_reduce_buffer().reshape(n32 + 1, n32)
+    S, ea = M[:nA, :nA].copy(), M[n32, :nA].copy()
+    ref.schur_reduce()
+    ref.schur_solve()
+    sc_ref = ref.backsub(mu)
+    dpa_ref = ref.get_dp()[:nA]
+    ref.upload_problem(prob)
+    want, _ = ref.levmar(max_iter=6, tr_handoff=False)
+    ref.close()
+
+    h = psba_amd.Psba(0)
+    h.set_solver(1, tol=1e-12, max_iter=2000)
+    h.upload_problem(prob)
+    assert h.schur_path() == 4
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    jk, val, ea_s = h.get_sparse_S()
+    it0, _, nb, nd = h.pcg_info()
+    assert nb == len(jk) and nd == n_cams * (n_cams + 1) // 2
+    if window is not None:
+        assert nb < 0.2 * nd  # the band and its wrap-around corner
+    scale = np.abs(S).max()
+    present = np.zeros((n_cams, n_cams), dtype=bool)
+    for (j, k), B in zip(jk, val):
+        assert k <= j
+        present[j, k] = True
+        want_blk = S[6 * j: 6 * j + 6, 6 * k: 6 * k + 6]
+        got = B if j != k else np.tril(B) + np.tril(B, -1).T
+        assert np.abs(got - want_blk).max() <= 1e-11 * scale, (j, k)
+    blocks = np.abs(S.reshape(n_cams, 6, n_cams, 6)).max(axis=(1, 3))
+    assert np.all(blocks[np.tril(~present)] == 0.0)  # what is not stored is exactly zero in the dense S
+    assert np.abs(ea_s - ea).max() <= 1e-10 * np.abs(ea).max()
+    h.schur_reduce()
+    h.schur_solve()
+    iters, relres, _, _ = h.pcg_info()
+    assert 0 < iters < 2000 and relres <= 1e-12
+    sc = h.backsub(mu)
+    assert sc.status == 0
+    dpa = h.get_dp()[:nA]
+    assert np.abs(dpa - dpa_ref).max() <= 1e-8 * np.abs(dpa_ref).max()
+    assert abs(sc.new_cost - sc_ref.new_cost) <= 1e-9 * sc_ref.new_cost
+    h.upload_problem(prob)
+    res, _ = h.levmar(max_iter=6, tr_handoff=False)
+    assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-8 * want.final_err
+    h.close()
+
+
 def test_sharded_dense_factorization_emulated_with_three_handles():
     """BASELINE configs[4] runs on 8 GPUs and its dense 12 000 x 12 000 factorization is 60 % of an LM
     iteration: replicated on every rank it would cap the scaling at 1.6x.  The two-level chain can
