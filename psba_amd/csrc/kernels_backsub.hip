@@ -80,15 +80,6 @@ __global__ __launch_bounds__(TILE_OBS) void k_backsub(BackArgs p) {
     const int a = o0 + tid;
     const int tn = tile + gridDim.x;
     const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
-    if (o1 - o0 > TILE_OBS) {  // a point seen by more cameras than a tile holds: k_backsub_long's
-      dsc = dn;
-      i = j = 0;
-      if (dsc.z + tid < dsc.w) {
-        i = p.iidx[dsc.z + tid];
-        j = p.jidx[dsc.z + tid];
-      }
-      continue;
-    }
     int pb0 = 0, pb1 = 0;  // CSR bounds of this thread's point
     if (p0 + tid < p1) {
       pb0 = p.ptr[p0 + tid] - o0;

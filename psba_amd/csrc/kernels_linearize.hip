@@ -56,15 +56,6 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
     const int a = o0 + tid;
     const int tn = tile + gridDim.x;
     const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
-    if (o1 - o0 > TILE_OBS) {  // a point seen by more cameras than a tile holds: k_linearize_long's
-      dsc = dn;
-      i = j = 0;
-      if (dsc.z + tid < dsc.w) {
-        i = p.iidx[dsc.z + tid];
-        j = p.jidx[dsc.z + tid];
-      }
-      continue;
-    }
     // CSR bounds of the (point, component) tasks of this thread (see below)
     constexpr int NTASK = (9 * TILE_PTS + TILE_OBS - 1) / TILE_OBS;  // rounds of (point, component) tasks
     int pb[NTASK][2];

@@ -779,11 +779,11 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
   a.mu = mu;
   a.nC = d.nC;
   a.nA = d.nA;
-  a.nTiles = d.nTiles;
+  a.nTiles = d.nTilesAll;  // (this kernel walks the contiguous partition and skips the long points' tiles itself)
   a.try_id = h->try_id;
   PSBA_HIP(h, hipMemsetAsync(h->red, 0, sizeof(double) * (size_t)(h->n32 + 1) * h->n32, h->stream));
   const bool owner = h->own_nwaves > 0 && !dump && !getenv("PSBA_SCHUR_ATOMIC");
-  int grid = d.nTiles < 2048 ? d.nTiles : 2048;
+  int grid = d.nTilesAll < 2048 ? d.nTilesAll : 2048;
   const size_t lds = sizeof(double) * (size_t)d.nA;  // e_a accumulators of a workgroup of the global-atomic kernel
   // (the owner route needs no dynamic LDS: the limit below is the global-atomic kernel's alone)
   if (!owner && lds > 100 * 1024)

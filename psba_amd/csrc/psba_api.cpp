@@ -304,7 +304,9 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   d.nA = 6 * nCams;
   d.nB = 3 * n3Dpts;
   d.nT = d.nA + d.nB;
-  d.nTiles = (int)tile_pt.size() - 1;
+  d.nTilesAll = (int)tile_pt.size() - 1;
+  d.nTiles = d.nTilesAll - (int)long_pts.size();  // the tile kernels never see a long point's tile
+  if (d.nTiles < 1) d.nTiles = 1;                 // (only long points: one empty tile keeps the grids non-empty)
   d.maxTrack = maxTrack;
   // K1 keeps 27 accumulators per camera in LDS while they fit beside its tile buffers (nC <= 455);
   // beyond that its camera sums go to global memory with fp64 atomics
@@ -527,9 +529,11 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, H2D(h->jidx, jidx, sizeof(int) * (size_t)d.nO));
   PSBA_HIP(h, H2D(h->ptr, ptr.data(), sizeof(int) * ptr.size()));
   PSBA_HIP(h, H2D(h->tile_pt, tile_pt.data(), sizeof(int) * tile_pt.size()));
-  std::vector<int4> tile_desc((size_t)d.nTiles);
-  for (int t = 0; t < d.nTiles; t++)
-    tile_desc[t] = make_int4(tile_pt[t], tile_pt[t + 1], ptr[tile_pt[t]], ptr[tile_pt[t + 1]]);
+  std::vector<int4> tile_desc;
+  for (int t = 0; t < d.nTilesAll; t++)
+    if (ptr[tile_pt[t + 1]] - ptr[tile_pt[t]] <= TILE_OBS)
+      tile_desc.push_back(make_int4(tile_pt[t], tile_pt[t + 1], ptr[tile_pt[t]], ptr[tile_pt[t + 1]]));
+  if (tile_desc.empty()) tile_desc.push_back(make_int4(0, 0, 0, 0));  // (only long points: an empty tile keeps the grids non-empty)
   PSBA_HIP(h, hipMemcpy(h->tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice));
   PSBA_HIP(h, hipMemsetAsync(h->dp, 0, sizeof(double) * d.nT, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope

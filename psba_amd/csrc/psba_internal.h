@@ -39,7 +39,8 @@ enum {
 struct Dims {
   int nC = 0, nP = 0, nO = 0;
   int nA = 0, nB = 0, nT = 0;
-  int nTiles = 0;
+  int nTiles = 0;     // tiles of the tile kernels (K1, K3): the long points' tiles are not among their descriptors
+  int nTilesAll = 0;  // tiles of the contiguous partition tile_pt (incl. one per long point)
   int maxTrack = 0;
 };
 

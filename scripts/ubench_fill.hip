@@ -19,7 +19,7 @@ __device__ __forceinline__ void dma16(const double2 *src, unsigned lds) {
 template <int MODE, int BATCH, int RUN7>
 __global__ __launch_bounds__(1024) void k_fill(const double2 *W2, int nrec, int nops_per_wave, double *out) {
   extern __shared__ double2 lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int stretch = (blockIdx.x % 8) + 8 * ((blockIdx.x / 8) % 2);
   const int my_lo = (int)((long long)nrec * stretch / 16), my_span = nrec / 16 - 80;
   double acc = 0;
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(1024) void k_fill(const double2 *W2, int nrec, int 
       // record loads and serialise them; the kernel reads its lists three steps ahead)
       const int it = i + b;
       const int lo = my_lo, span = my_span;
-      const int a0 = lo + (int)(((long long)span * it) / nops_per_wave) + ((it * 37 + wave * 11) & 63);
+      const int a0 = __builtin_amdgcn_readfirstlane(lo + (int)(((long long)span * it) / nops_per_wave) + ((it * 37 + wave * 11) & 63));
       const int n = RUN7 ? 7 : 1 + ((it * 5 + wave) % 7);
-      const int slot = ((it * 131 + wave * 57) % 960);
+      const int slot = __builtin_amdgcn_readfirstlane((it * 131 + wave * 57) % 960);
       ns[b] = n;
       dsts[b] = slot * 9;
       if (MODE == 0) {
