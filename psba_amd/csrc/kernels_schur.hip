@@ -227,8 +227,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
 
   const long long s1 = (MODE == 4) ? wg.item0 : wg.item1;
   double keep = 0.0;
+  // the next item word is fetched a turn ahead: its latency would otherwise sit in front of the
+  // record loads of every turn (a wave has only about six turns)
+  unsigned long long item_next = (wg.item0 + tid < s1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
   for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
-    const unsigned long long item = p.items[t];
+    const unsigned long long item = item_next;
+    if (t + SCHUR_THREADS < s1) item_next = p.items[t + SCHUR_THREADS];
     if (item == SCHUR_NULL_ITEM) continue;
     const int a = wg.obs0 + (int)(item & ((1u << ITEM_OBS_BITS) - 1));
     const int i = wg.pt0 + (int)((item >> ITEM_OBS_BITS) & ((1u << ITEM_PT_BITS) - 1));
@@ -240,16 +244,31 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
     const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
     const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
     double v[6], vi[6], w[18], wb[18];
+    double g0, g1, g2;
+    if (MODE == 12 || MODE == 13) {
+      // no record loads at all: operands made up from the item word (arithmetic and atomics only)
+      const double base = 1.0 + 1e-3 * (double)(item & 1023);
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = (k == 0 || k == 3 || k == 5) ? 4.0 + base : 0.25 * base;
+      g0 = base; g1 = base + 1.0; g2 = base + 2.0;
+#pragma unroll
+      for (int k = 0; k < 18; k++) {
+        w[k] = base + k;
+        wb[k] = base - k;
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = pv[k];
-    const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+    g0 = pv[6], g1 = pv[7], g2 = pv[8];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
       const double2 q = wa[k];
       w[2 * k] = q.x;
       w[2 * k + 1] = q.y;
     }
-    if (MODE == 3) {  // products without the W_b loads
+    }
+    if (MODE == 12 || MODE == 13) {
+    } else if (MODE == 3) {  // products without the W_b loads
 #pragma unroll
       for (int k = 0; k < 18; k++) wb[k] = w[k] + 1.0;
     } else if (MODE != 2) {
@@ -271,6 +290,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
     }
     const bool self = boff == 0;
+    // Y carries the sign of the product: Y = -W_a V*^-1, so that neither the 36 values nor the
+    // e_a terms need a sign flip of their own
+#pragma unroll
+    for (int k = 0; k < 6; k++) vi[k] = -vi[k];
     double Y[18], e[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -278,11 +301,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
       Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
       Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
-      e[r] = -(Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2);
+      e[r] = Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2;
     }
     if (DUMP && self) {
 #pragma unroll
-      for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = Y[k];
+      for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = -Y[k];
     }
     if (MODE == 2) {
       keep += Y[0] + Y[17] + e[0] + e[5];
@@ -294,19 +317,52 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       for (int rc = 0; rc < 36; rc++) atomicAdd(&blk[rc], wb[rc % 18]);
       continue;
     }
+    if (MODE == 10 || MODE == 11) {
+#pragma unroll
+      for (int k = 0; k < 18; k++) asm volatile("" ::"v"(w[k]));
+      asm volatile("" ::"v"(g0), "v"(g1), "v"(g2));
+#pragma unroll
+      for (int rc = 0; rc < 36; rc++) {
+        if (MODE == 10)
+          atomicAdd(&blk[rc], wb[rc % 18]);
+        else
+          atomicAdd(reinterpret_cast<unsigned long long *>(&blk[rc]), (unsigned long long)__double_as_longlong(wb[rc % 18]));
+      }
+      continue;
+    }
+    if (MODE == 8) {
+#pragma unroll
+      for (int rc = 0; rc < 36; rc++)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&blk[rc]), (unsigned long long)__double_as_longlong(wb[rc % 18]));
+      continue;
+    }
+    // a row of the block at a time: its six values are independent chains of three operations,
+    // formed side by side (one after the other, every operation would wait for the one before)
 #pragma unroll
     for (int r = 0; r < 6; r++) {
+      double val[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) val[c] = Y[3 * r] * wb[3 * c];
+#pragma unroll
+      for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 1], wb[3 * c + 1], val[c]);
+#pragma unroll
+      for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 2], wb[3 * c + 2], val[c]);
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
-        double val = -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2);
         // the self-product's e_a terms ride in redundant upper-triangle slots (EA_SLOT)
-        if (r == 0 && c >= 1) val = self ? e[c - 1] : val;
-        if (r == 1 && c == 2) val = self ? e[5] : val;
+        if (r == 0 && c >= 1) val[c] = self ? e[c - 1] : val[c];
+        if (r == 1 && c == 2) val[c] = self ? e[5] : val[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
         if (MODE == 1)
-          keep += val;
+          keep += val[c];
+        else if (MODE == 9)
+          asm volatile("" ::"v"(val[c]));
+        else if (MODE == 7 || MODE == 13)
+          atomicAdd(reinterpret_cast<unsigned long long *>(&blk[6 * r + c]), (unsigned long long)__double_as_longlong(val[c]));
         else
-          atomicAdd(&blk[6 * r + c], val);
+          atomicAdd(&blk[6 * r + c], val[c]);
       }
     }
   }
@@ -687,6 +743,20 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
         hipLaunchKernelGGL((k_schur_lds<false, 5>), G, B, lds, h->stream, a);
       else if (mode == 6)
         hipLaunchKernelGGL((k_schur_lds<false, 6>), G, B, lds, h->stream, a);
+      else if (mode == 7)
+        hipLaunchKernelGGL((k_schur_lds<false, 7>), G, B, lds, h->stream, a);
+      else if (mode == 8)
+        hipLaunchKernelGGL((k_schur_lds<false, 8>), G, B, lds, h->stream, a);
+      else if (mode == 9)
+        hipLaunchKernelGGL((k_schur_lds<false, 9>), G, B, lds, h->stream, a);
+      else if (mode == 10)
+        hipLaunchKernelGGL((k_schur_lds<false, 10>), G, B, lds, h->stream, a);
+      else if (mode == 11)
+        hipLaunchKernelGGL((k_schur_lds<false, 11>), G, B, lds, h->stream, a);
+      else if (mode == 12)
+        hipLaunchKernelGGL((k_schur_lds<false, 12>), G, B, lds, h->stream, a);
+      else if (mode == 13)
+        hipLaunchKernelGGL((k_schur_lds<false, 13>), G, B, lds, h->stream, a);
       else
         hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
     }
