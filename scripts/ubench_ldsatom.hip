@@ -18,15 +18,16 @@ constexpr double GHZ = 2.4;
 // KIND 0: ds_add_f64  1: ds_add_u64  2: ds_add_u32  3: ds_add_f32  4: read-add-write b64 (not atomic)
 // 5: ds_add_f64 with only the even lanes active  6: ds_add_f64, lanes of the upper half-wave 18 doubles on
 // 7: ds_add_rtn_u64  8: ds_max_u64 (another 64-bit integer op)
+// 9: ds_read_b128 + two adds + ds_write_b128 (not atomic; block stride 38 doubles for the alignment), 18 per turn
 template <int KIND, int NA>
 __global__ __launch_bounds__(1024) void k_add(const int *pos, int iters, int nblk, double *out) {
   extern __shared__ double sm[];
-  for (int t = threadIdx.x; t < 37 * nblk; t += blockDim.x) sm[t] = 0;
+  for (int t = threadIdx.x; t < 38 * nblk; t += blockDim.x) sm[t] = 0;
   __syncthreads();
   const int *r = pos + ((size_t)blockIdx.x * iters) * blockDim.x + threadIdx.x;
   unsigned long long keep = 0;
   for (int it = 0; it < iters; it++) {
-    double *b = sm + 37 * r[(size_t)it * blockDim.x];
+    double *b = sm + (KIND == 9 ? 38 : 37) * r[(size_t)it * blockDim.x];
     if (KIND == 6) b += (threadIdx.x & 32) ? 18 : 0;
     if (KIND == 5 && (threadIdx.x & 1)) continue;
 #pragma unroll
@@ -38,6 +39,13 @@ __global__ __launch_bounds__(1024) void k_add(const int *pos, int iters, int nbl
       if (KIND == 4) b[k] += 1.0 + k;
       if (KIND == 7) keep += atomicAdd(reinterpret_cast<unsigned long long *>(&b[k]), (unsigned long long)(k + 1 + it));
       if (KIND == 8) atomicMax(reinterpret_cast<unsigned long long *>(&b[k]), (unsigned long long)(k + 1 + it));
+      if (KIND == 9) {
+        double2 *q = reinterpret_cast<double2 *>(b) + k;
+        double2 x = *q;
+        x.x += 1.0 + k;
+        x.y += 2.0 + k;
+        *q = x;
+      }
     }
   }
   __syncthreads();
@@ -55,7 +63,7 @@ int main() {
   int *d; CK(hipMalloc(&d, n * 4));
   const char *pats[] = {"16 lanes distinct mod 16", "random blocks", "32 lanes distinct mod 32"};
   const char *kinds[] = {"ds_add_f64", "ds_add_u64", "ds_add_u32", "ds_add_f32", "read+add+write b64", "ds_add_f64 even lanes only",
-                         "ds_add_f64 upper half +18", "ds_add_rtn_u64", "ds_max_u64"};
+                         "ds_add_f64 upper half +18", "ds_add_rtn_u64", "ds_max_u64", "read+2 adds+write b128 (x18)"};
   for (int pat = 0; pat < 3; pat++) {
     for (size_t base = 0; base < n; base += 32) {
       int perm[32];
@@ -73,10 +81,10 @@ int main() {
       }
     }
     CK(hipMemcpy(d, pos.data(), n * 4, hipMemcpyHostToDevice));
-    for (int kind = 0; kind < 9; kind++) {
+    for (int kind = 0; kind < 10; kind++) {
       for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(e0));
-        const size_t lds = nblk * 37 * 8;
+        const size_t lds = nblk * 38 * 8;
         switch (kind) {
           case 0: k_add<0, 36><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
           case 1: k_add<1, 36><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
@@ -87,11 +95,12 @@ int main() {
           case 6: k_add<6, 18><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
           case 7: k_add<7, 36><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
           case 8: k_add<8, 36><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
+          case 9: k_add<9, 18><<<NCU, threads, lds>>>(d, iters, nblk, out); break;
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       }
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      const double instr_per_cu = (double)iters * (kind == 6 ? 18 : 36) * (threads / 64);
+      const double instr_per_cu = (double)iters * (kind == 6 || kind == 9 ? 18 : 36) * (threads / 64);
       printf("%-28s %-26s %8.1f us  %6.2f cyc/instr/CU\n", kinds[kind], pats[pat], 1e3 * ms, ms * 1e-3 * GHZ * 1e9 / instr_per_cu);
     }
   }
