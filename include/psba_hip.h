@@ -336,6 +336,8 @@ int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
  * ||S x - e_a|| <= tol ||e_a|| or max_iter iterations; a diagonal block that is not positive definite or
  * a direction of non-positive curvature reports PSBA_NOT_SPD, so psba_levmar works unchanged.  The
  * sba_func.h mirror verbs and the trust-region operators need the dense S and refuse this mode.
+ * Single rank only: the block lists of sharded points would differ between ranks (psba_upload_problem and
+ * psba_set_rank_layout refuse the combination).
  * psba_set_solver: before psba_upload_problem; tol <= 0 / max_iter <= 0 keep 1e-10 / 500. */
 #define PSBA_SOLVER_DENSE 0
 #define PSBA_SOLVER_PCG 1

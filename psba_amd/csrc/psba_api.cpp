@@ -258,6 +258,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !Kparas || !impts || !initrot || !camsEx ||
       !pts3D || !iidx || !jidx)
     return fail(h, PSBA_E_INVALID, "psba_upload_problem: null pointer or non-positive size");
+  // every rank would derive its own block list from its own points: the lists (and the diagonal blocks'
+  // U + mu) do not line up under a sum over ranks, and no exchange of the block pattern is built
+  if (h->solver == PSBA_SOLVER_PCG && h->nranks > 1)
+    return fail(h, PSBA_E_INVALID, "PSBA_SOLVER_PCG is single-rank: the block-sparse S of sharded points is not built");
   PSBA_HIP(h, hipSetDevice(h->device));
   // ---- index build: point CSR + point-aligned tiles (replaces generate_idxs) ----
   std::vector<int> ptr((size_t)n3Dpts + 1, 0);
@@ -1273,6 +1277,7 @@ int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
   CHECK_H(h);
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSBA_E_INVALID, "bad rank %d / %d", rank, nranks);
   if (h->comm) return fail(h, PSBA_E_STATE, "a communicator is attached: its layout is fixed");
+  if (h->solver == PSBA_SOLVER_PCG && nranks > 1) return fail(h, PSBA_E_INVALID, "PSBA_SOLVER_PCG is single-rank");
   h->nranks = nranks;
   h->rank = rank;
   return PSBA_OK;

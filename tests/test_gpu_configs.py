@@ -373,6 +373,7 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     default route block by block, absent blocks exactly zero there, dpa against the dense
     factorization's at 1e-8, and the LM run through the iterative solve against the dense one."""
     import psba_amd
+    from psba_amd import capi
     import psba_amd.synth as synth
     prob = synth.make_problem(n_cams=n_cams, n_pts=6000, mean_track=5.0, seed=77 + n_cams, window=window)
     ref = psba_amd.Psba(0)
@@ -426,6 +427,15 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     h.upload_problem(prob)
     res, _ = h.levmar(max_iter=6, tr_handoff=False)
     assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-8 * want.final_err
+    # sharded points would give every rank its own block list: the combination is refused, not summed wrongly
+    with pytest.raises(capi.PsbaError):
+        h.set_rank_layout(2, 0)
+    h.close()
+    h = psba_amd.Psba(0)
+    h.set_rank_layout(2, 0)
+    h.set_solver(1)
+    with pytest.raises(capi.PsbaError):
+        h.upload_problem(prob)
     h.close()
 
 
