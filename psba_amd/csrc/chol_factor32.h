@@ -67,8 +67,12 @@ __device__ __forceinline__ void f32_wait(int *flag, int v) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void f32_post(int *flag, int v, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_store((lds_int *)flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // no release fence: everything the flag announces went to the LDS from this wave before it, and
+  // the LDS executes a wave's operations in order -- a fence here is an s_waitcnt lgkmcnt(0), i.e. a
+  // full LDS round trip of the serial wave per panel.  (The compiler barriers keep the order.)
+  asm volatile("" ::: "memory");
+  if (lane == 0) *(volatile lds_int *)flag = v;
+  asm volatile("" ::: "memory");
 }
 
 // 1 / d to full precision: v_rcp_f64 is good to ~2^-24, one cubic step (e + e^2) finishes it
