@@ -336,8 +336,12 @@ int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
  * ||S x - e_a|| <= tol ||e_a|| or max_iter iterations; a diagonal block that is not positive definite or
  * a direction of non-positive curvature reports PSBA_NOT_SPD, so psba_levmar works unchanged.  The
  * sba_func.h mirror verbs and the trust-region operators need the dense S and refuse this mode.
- * Single rank only: the block lists of sharded points would differ between ranks (psba_upload_problem and
- * psba_set_rank_layout refuse the combination).
+ * Sharded points: every rank must hold the same block list, the union of the blocks its ranks' points
+ * produce.  With a communicator psba_upload_problem forms it by itself (one max all-reduce of a byte per
+ * block); a host with its own transport computes psba_sparse_pattern on every rank (host only, no
+ * handle), ORs the flags, and hands them to psba_set_sparse_pattern before psba_upload_problem; between
+ * psba_schur_assemble and psba_schur_solve it then sums psba_get_sparse_S over the ranks and returns the
+ * sums with psba_set_sparse_S (the conjugate gradients themselves run replicated on every rank).
  * psba_set_solver: before psba_upload_problem; tol <= 0 / max_iter <= 0 keep 1e-10 / 500. */
 #define PSBA_SOLVER_DENSE 0
 #define PSBA_SOLVER_PCG 1
@@ -346,6 +350,10 @@ int psba_set_solver(psba_handle h, int solver, double tol, int max_iter);
 int psba_pcg_info(psba_handle h, int *iters, double *relres, long long *blocks, long long *dense_blocks);
 /* the assembled blocks: jk[2 blocks] = (j, k), k <= j; val[36 blocks] row-major; ea[nA]; any pointer may be NULL */
 int psba_get_sparse_S(psba_handle h, int *jk, double *val, double *ea);
+int psba_set_sparse_S(psba_handle h, const double *val, const double *ea);
+/* flags[nCams (nCams + 1) / 2]: 1 where block tri(j) + k (k <= j) has a product, i.e. cameras j and k see a common point */
+int psba_sparse_pattern(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, const int *jidx, unsigned char *flags);
+int psba_set_sparse_pattern(psba_handle h, const unsigned char *flags, long long n);
 
 /* ---- the dense factorization sharded over ranks (large matrices: the two-level chain) --------------
  * The reference factors S on one device (PSBA/cl_spdinv.cpp:18-40, CL_files/SPD_inv.cl:165-179).

@@ -136,6 +136,9 @@ SIGNATURES = [
     ("psba_set_solver", C.c_int, [_h, C.c_int, C.c_double, C.c_int]),
     ("psba_pcg_info", C.c_int, [_h, _ip, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     ("psba_get_sparse_S", C.c_int, [_h, _ip, _dp, _dp]),
+    ("psba_set_sparse_S", C.c_int, [_h, _dp, _dp]),
+    ("psba_sparse_pattern", C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
+    ("psba_set_sparse_pattern", C.c_int, [_h, C.POINTER(C.c_ubyte), C.c_longlong]),
     ("psba_chol_dist_shape", C.c_int, [_h, _ip, _ip, _ip]),
     ("psba_chol_dist_begin", C.c_int, [_h]),
     ("psba_chol_dist_superpanel", C.c_int, [_h, C.c_int]),
@@ -176,6 +179,19 @@ def _c(a, dt=np.float64):
 
 class Problem(dict):
     """K[nC,5] initrot[nC,4] cams[nC,6] pts[nP,3] impts[nO,2] iidx[nO] jidx[nO] nC nP nO."""
+
+
+def sparse_pattern(prob):
+    """psba_sparse_pattern (host only): one byte per block tri(j) + k of the lower block triangle."""
+    nC = int(prob["nC"])
+    flags = np.zeros(nC * (nC + 1) // 2, dtype=np.uint8)
+    ii = np.ascontiguousarray(prob["iidx"], dtype=np.int32)
+    jj = np.ascontiguousarray(prob["jidx"], dtype=np.int32)
+    rc = lib.psba_sparse_pattern(nC, int(prob["nP"]), int(prob["nO"]), _i(ii), _i(jj),
+                                 flags.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if rc != 0:
+        raise PsbaError(rc, "psba_sparse_pattern failed")
+    return flags
 
 
 def read_problem(cams_file, pts_file, fixedK=None):
@@ -489,6 +505,15 @@ class Psba:
         ea = np.empty(6 * self.nC)
         self._ck(lib.psba_get_sparse_S(self._h, _i(jk), _d(val), _d(ea)))
         return jk, val, ea
+
+    def set_sparse_S(self, val, ea):
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        ea = np.ascontiguousarray(ea, dtype=np.float64)
+        self._ck(lib.psba_set_sparse_S(self._h, _d(val), _d(ea)))
+
+    def set_sparse_pattern(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._ck(lib.psba_set_sparse_pattern(self._h, flags.ctypes.data_as(C.POINTER(C.c_ubyte)), flags.size))
 
     # ---- the sharded dense factorization, piece by piece ----
     def chol_dist_shape(self):

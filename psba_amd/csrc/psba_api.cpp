@@ -258,10 +258,6 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !Kparas || !impts || !initrot || !camsEx ||
       !pts3D || !iidx || !jidx)
     return fail(h, PSBA_E_INVALID, "psba_upload_problem: null pointer or non-positive size");
-  // every rank would derive its own block list from its own points: the lists (and the diagonal blocks'
-  // U + mu) do not line up under a sum over ranks, and no exchange of the block pattern is built
-  if (h->solver == PSBA_SOLVER_PCG && h->nranks > 1)
-    return fail(h, PSBA_E_INVALID, "PSBA_SOLVER_PCG is single-rank: the block-sparse S of sharded points is not built");
   PSBA_HIP(h, hipSetDevice(h->device));
   // ---- index build: point CSR + point-aligned tiles (replaces generate_idxs) ----
   std::vector<int> ptr((size_t)n3Dpts + 1, 0);
@@ -394,7 +390,32 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   if (sparse) {
     // block-sparse S: the owner route's product lists give the blocks that exist
     OwnerPlanHost op;
-    TRY(build_owner_plan(nCams, n2Dprojs, iidx, jidx, ptr.data(), op));
+    // sharded points: every rank must hold the same block list, the union of what the ranks' points
+    // produce -- one byte per block of the lower triangle, combined with a max all-reduce over the
+    // communicator, or handed in by a host that has its own transport (psba_set_sparse_pattern)
+    std::vector<unsigned char> pat;
+    if (h->nranks > 1) {
+      const size_t nBlk = (size_t)nCams * (nCams + 1) / 2;
+      if (h->comm) {
+        pat.resize(nBlk);
+        TRY(sparse_pattern(nCams, n2Dprojs, iidx, jidx, ptr.data(), pat.data()));
+        unsigned char *dev = nullptr;
+        PSBA_HIP(h, hipMalloc((void **)&dev, nBlk));
+        hipError_t e1 = hipMemcpyAsync(dev, pat.data(), nBlk, hipMemcpyHostToDevice, h->stream);
+        ncclResult_t e2 = e1 == hipSuccess ? ncclAllReduce(dev, dev, nBlk, ncclUint8, ncclMax, h->comm, h->stream) : ncclSuccess;
+        if (e1 == hipSuccess && e2 == ncclSuccess) e1 = hipMemcpyAsync(pat.data(), dev, nBlk, hipMemcpyDeviceToHost, h->stream);
+        if (e1 == hipSuccess && e2 == ncclSuccess) e1 = hipStreamSynchronize(h->stream);
+        (void)hipFree(dev);
+        if (e2 != ncclSuccess) return fail(h, PSBA_E_RCCL, "all-reduce of the block pattern: %s", ncclGetErrorString(e2));
+        PSBA_HIP(h, e1);
+      } else {
+        if (h->bs_pattern.size() != nBlk)
+          return fail(h, PSBA_E_STATE, "PSBA_SOLVER_PCG with a rank layout and no communicator: psba_set_sparse_pattern "
+                                       "(the union of psba_sparse_pattern over the ranks) before psba_upload_problem");
+        pat = h->bs_pattern;
+      }
+    }
+    TRY(build_owner_plan(nCams, n2Dprojs, iidx, jidx, ptr.data(), op, pat.empty() ? nullptr : pat.data()));
     h->nGroups = 0;
     h->packedN = 36 * (size_t)nCams * (nCams + 1) / 2;
     TRY(dev_alloc(h, &h->own_prod, op.prod.size()));
@@ -941,6 +962,38 @@ int psba_get_sparse_S(psba_handle h, int *jk, double *val, double *ea) {
   return PSBA_OK;
 }
 
+// the counterpart for a host that sums the ranks' blocks itself (between psba_schur_assemble and psba_schur_solve)
+int psba_set_sparse_S(psba_handle h, const double *val, const double *ea) {
+  CHECK_H(h);
+  NEED(h, h->assembled && h->solver == PSBA_SOLVER_PCG, "psba_schur_assemble with PSBA_SOLVER_PCG first");
+  if (val) PSBA_HIP(h, hipMemcpyAsync(h->bs_val, val, sizeof(double) * 36 * (size_t)h->bs_nblk, hipMemcpyHostToDevice, h->stream));
+  if (ea) PSBA_HIP(h, hipMemcpyAsync(h->bs_ea, ea, sizeof(double) * (size_t)h->d.nA, hipMemcpyHostToDevice, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  h->solved = h->backsubbed = false;
+  return PSBA_OK;
+}
+
+// host only: which blocks of the lower block triangle a (shard of a) problem produces
+int psba_sparse_pattern(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, const int *jidx, unsigned char *flags) {
+  if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !iidx || !jidx || !flags) return PSBA_E_INVALID;
+  std::vector<int> ptr((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return PSBA_E_INVALID;
+    if (a && iidx[a] < iidx[a - 1]) return PSBA_E_INVALID;  // point-major, as psba_upload_problem requires
+    ptr[(size_t)iidx[a] + 1]++;
+  }
+  for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[(size_t)i];
+  return psba::sparse_pattern(nCams, n2Dprojs, iidx, jidx, ptr.data(), flags);
+}
+
+int psba_set_sparse_pattern(psba_handle h, const unsigned char *flags, long long n) {
+  CHECK_H(h);
+  if (!flags || n <= 0) return fail(h, PSBA_E_INVALID, "psba_set_sparse_pattern: null pattern");
+  NEED(h, !h->uploaded, "psba_set_sparse_pattern before psba_upload_problem (the block list depends on it)");
+  h->bs_pattern.assign(flags, flags + n);
+  return PSBA_OK;
+}
+
 int psba_allreduce_scalars(psba_handle h, double *v, int n) {
   CHECK_H(h);
   if (!v || n < 0 || n > 8) return fail(h, PSBA_E_INVALID, "psba_allreduce_scalars: at most 8 values");
@@ -1277,7 +1330,8 @@ int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
   CHECK_H(h);
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSBA_E_INVALID, "bad rank %d / %d", rank, nranks);
   if (h->comm) return fail(h, PSBA_E_STATE, "a communicator is attached: its layout is fixed");
-  if (h->solver == PSBA_SOLVER_PCG && nranks > 1) return fail(h, PSBA_E_INVALID, "PSBA_SOLVER_PCG is single-rank");
+  if (h->solver == PSBA_SOLVER_PCG && h->uploaded && nranks != h->nranks)
+    return fail(h, PSBA_E_STATE, "PSBA_SOLVER_PCG: the rank layout is part of the block list, set it before psba_upload_problem");
   h->nranks = nranks;
   h->rank = rank;
   return PSBA_OK;

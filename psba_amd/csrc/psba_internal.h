@@ -234,6 +234,7 @@ struct psba_ctx {
   double *pcg_vec = nullptr;    // r | z | p | q, nA each
   double *pcg_minv = nullptr;   // [nC][36] inverses of the diagonal blocks
   double *pcg_scal = nullptr, *pcg_host = nullptr;  // device scalars and their pinned mirror
+  std::vector<unsigned char> bs_pattern;  // sharded points without a communicator: the union of all ranks' blocks (psba_set_sparse_pattern)
   // K2 owner route (many cameras): see OwnerPlanHost
   int2 *own_prod = nullptr;
   psba::OwnerWave *own_waves = nullptr;
@@ -310,7 +311,9 @@ int launch_max_diag(psba_ctx *h);
 // kernels_schur.hip
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
                      const int *ptr, SchurPlanHost &out);
-int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out);
+int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out,
+                     const unsigned char *pattern = nullptr);
+int sparse_pattern(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, unsigned char *flags);
 int build_ring_plan(int nCams, int nPts, int nObs, const int *iidx, const int *jidx, const int *ptr, RingPlanHost &out,
                     bool force = false);
 int launch_schur_ring(psba_ctx *h, double mu, bool dump);

@@ -292,7 +292,8 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
 // are sorted by length (longest first) and dealt 64 to a wave; a wave's products go into
 // ELL rows [t][lane].  LMAX aims at >= 256 k units so that every SIMD has several waves, but not
 // below 16 products per unit (shorter units would only multiply the atomic adds of the combine).
-int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out) {
+int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out,
+                     const unsigned char *pattern) {
   const long long nBlk = tri(nCams);
   std::vector<long long> cnt((size_t)nBlk + 1, 0);
   long long total = 0;
@@ -313,14 +314,16 @@ int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, cons
   long long LMAX = (total + 262143) / 262144;
   if (LMAX < 16) LMAX = 16;
   if (const char *e = getenv("PSBA_OWNER_LMAX")) LMAX = atoll(e) > 0 ? atoll(e) : LMAX;
-  // the blocks that exist: every diagonal block, and the off-diagonal ones with at least one product
+  // the blocks that exist: every diagonal block, and the off-diagonal ones with at least one product --
+  // here, or (sharded points: `pattern`, one byte per block of the lower triangle) on any rank, so that
+  // the block lists of all ranks are the same list
   out.blocks.clear();
   out.diag_slot.assign((size_t)nCams, 0);
   std::vector<int> slot_of((size_t)nBlk, -1);
   for (int j = 0; j < nCams; j++)
     for (int k = 0; k <= j; k++) {
       const long long blk = tri(j) + k;
-      if (k == j || cnt[(size_t)blk + 1] > cnt[(size_t)blk]) {
+      if (k == j || cnt[(size_t)blk + 1] > cnt[(size_t)blk] || (pattern && pattern[(size_t)blk])) {
         slot_of[(size_t)blk] = (int)out.blocks.size();
         if (k == j) out.diag_slot[(size_t)j] = (int)out.blocks.size();
         out.blocks.push_back(make_int2(j, k));
@@ -358,6 +361,17 @@ int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, cons
   }
   for (size_t u = units.size(); u < nW * 64; u++) out.units[u] = {0, 0, 1, -1};  // idle lanes (slot = -1)
   out.products = total;
+  return PSBA_OK;
+}
+
+// one byte per block tri(j) + k of the lower block triangle: 1 where cameras j and k see a common point
+int sparse_pattern(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, unsigned char *flags) {
+  const long long nBlk = tri(nCams);
+  for (long long t = 0; t < nBlk; t++) flags[t] = 0;
+  for (int a = 0; a < nObs; a++) {
+    const long long base = tri(jidx[a]);
+    for (int b = ptr[iidx[a]]; b <= a; b++) flags[base + jidx[b]] = 1;
+  }
   return PSBA_OK;
 }
 

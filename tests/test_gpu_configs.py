@@ -427,16 +427,77 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     h.upload_problem(prob)
     res, _ = h.levmar(max_iter=6, tr_handoff=False)
     assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-8 * want.final_err
-    # sharded points would give every rank its own block list: the combination is refused, not summed wrongly
+    # the rank layout is part of the block list: it cannot change under an uploaded sparse problem
     with pytest.raises(capi.PsbaError):
         h.set_rank_layout(2, 0)
     h.close()
+    # sharded points without a communicator and without the union pattern: refused, not summed wrongly
     h = psba_amd.Psba(0)
     h.set_rank_layout(2, 0)
     h.set_solver(1)
     with pytest.raises(capi.PsbaError):
-        h.upload_problem(prob)
+        h.upload_problem(capi.shard_problem(prob, 2, 0))
     h.close()
+
+
+def test_block_sparse_S_with_sharded_points():
+    """The block-sparse route under a rank layout: every rank's block list is the union of the blocks all
+    ranks' points produce (psba_sparse_pattern per shard, OR-ed by the host, psba_set_sparse_pattern -- what
+    psba_upload_problem does by itself over a communicator), so the lists line up and the sum over ranks
+    is a plain sum of the value arrays (psba_get / set_sparse_S); mu is added by rank 0 only, U and g_a
+    are per-rank partial sums.  Three handles on one GPU: the summed blocks against the single-handle
+    assembly block by block, the replicated conjugate-gradient solve and the try's scalars against it."""
+    import psba_amd
+    from psba_amd import capi
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=240, n_pts=3000, mean_track=4.0, seed=991, window=24)
+    ref = psba_amd.Psba(0)
+    ref.set_solver(1, tol=1e-12, max_iter=2000)
+    ref.upload_problem(prob)
+    ref.linearize(1.0, 1.0)
+    mu = 1e-3 * ref.max_diag()
+    ref.schur_assemble(mu); ref.schur_reduce()
+    jk_ref, val_ref, ea_ref = ref.get_sparse_S()
+    ref.schur_solve()
+    dpa_ref = ref.get_dp()[: 6 * 240].copy()
+    want = ref.backsub(mu)
+    nr = 3
+    shards = [capi.shard_problem(prob, nr, r) for r in range(nr)]
+    pats = [capi.sparse_pattern(s) for s in shards]
+    union = np.maximum.reduce(pats)
+    assert np.array_equal(union, capi.sparse_pattern(prob))   # the shards' patterns OR to the whole problem's
+    assert any(not np.array_equal(p, union) for p in pats)    # ... and differ from each other: the case that needs the union
+    hs = []
+    for r in range(nr):
+        h = psba_amd.Psba(0)
+        h.set_rank_layout(nr, r)
+        h.set_solver(1, tol=1e-12, max_iter=2000)
+        h.set_sparse_pattern(union)
+        h.upload_problem(shards[r])
+        h.linearize(1.0, 1.0)
+        h.schur_assemble(mu)
+        hs.append(h)
+    parts = [h.get_sparse_S() for h in hs]
+    for jk, _, _ in parts:
+        assert np.array_equal(jk, jk_ref)
+    val = sum(p[1] for p in parts)
+    ea = sum(p[2] for p in parts)
+    scale = np.abs(val_ref).max()
+    assert np.abs(val - val_ref).max() <= 1e-11 * scale
+    assert np.abs(ea - ea_ref).max() <= 1e-10 * np.abs(ea_ref).max()
+    got = np.zeros(4)
+    for h in hs:
+        h.set_sparse_S(val, ea)
+        h.schur_solve()
+        dpa = h.get_dp()[: 6 * 240]
+        assert np.abs(dpa - dpa_ref).max() <= 1e-8 * np.abs(dpa_ref).max()
+        sc = h.backsub(mu)
+        assert sc.status == 0
+        got += [sc.dp_l2, sc.gain_den, sc.new_cost, sc.newp_l2]
+    for g, w in zip(got, [want.dp_l2, want.gain_den, want.new_cost, want.newp_l2]):
+        assert abs(g - w) <= 1e-8 * abs(w), (g, w)
+    for h in hs + [ref]:
+        h.close()
 
 
 def test_sharded_dense_factorization_emulated_with_three_handles():

@@ -343,3 +343,24 @@ def test_bal_converter(tmp_path):
         x, y = [(o[2], o[3]) for o in obs if o[0] == j and o[1] == i][0]
         want = np.array([x - p[0], -(y - p[1])])  # y axis flipped
         np.testing.assert_allclose(ex[a], want, rtol=0, atol=1e-9)
+
+
+def test_sparse_pattern_is_the_covisibility_of_camera_pairs():
+    """psba_sparse_pattern (host only): block tri(j) + k of the lower block triangle is flagged exactly when
+    cameras j and k see a common point (every camera with an observation flags its diagonal block); the
+    patterns of point shards OR to the pattern of the whole problem -- what the block-sparse route under
+    a rank layout relies on."""
+    from psba_amd import capi, synth
+    prob = synth.make_problem(n_cams=30, n_pts=200, mean_track=3.5, seed=5, window=8)
+    nC = prob["nC"]
+    want = np.zeros((nC, nC), dtype=bool)
+    ii, jj = prob["iidx"], prob["jidx"]
+    for i in range(prob["nP"]):
+        cams = jj[ii == i]
+        want[np.ix_(cams, cams)] = True
+    flags = capi.sparse_pattern(prob)
+    for j in range(nC):
+        for k in range(j + 1):
+            assert bool(flags[j * (j + 1) // 2 + k]) == bool(want[j, k]), (j, k)
+    parts = [capi.sparse_pattern(capi.shard_problem(prob, 3, r)) for r in range(3)]
+    assert np.array_equal(np.maximum.reduce(parts), flags)
