@@ -440,7 +440,7 @@ __device__ __forceinline__ void wide4_block(double *Lw, const double *Lx, int ld
 // Workgroup 0: the next diagonal block + its factorization and the e_a tile row's first tiles are as
 // in k_cholg_update_wide; every other wave owns one 64x64 block of the lower triangle of the
 // trailing square, or one tile of the e_a tile row.
-// nranks > 1: the factorization is sharded -- this rank updates only the 64-column blocks it owns
+// nranks > 0: the factorization is sharded (0 = the replicated chain; 1 = a one-rank exchange, the test hook) -- this rank updates only the 64-column blocks it owns
 // (absolute block B = column / 64, owner B % nranks; the e_a tiles of those columns with them); the
 // owners send a super-panel's columns to everybody before it is factored (launch_chol_graph), and the
 // next diagonal block is factored after that exchange by k_cholg_diag (workgroup 0's look-ahead would
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   if (blockIdx.x == 0) {
-    if (nranks > 1) return;
+    if (nranks > 0) return;
     if (tid < 4) s.flag[tid] = 0;
     if (tid == 4) s.fail = 0;
     if (wave < 3) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   if (idx >= ntri) {
     const long long e = idx - ntri;  // e_a tile row
     if (e >= nTl) return;
-    if (nranks > 1 && (Tw + (int)e) / 4 % nranks != rank) return;
+    if (nranks > 0 && (Tw + (int)e) / 4 % nranks != rank) return;
     const int TC = Tw + (int)e;
     store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
     return;
@@ -485,11 +485,11 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   while ((long long)m * (m + 1) / 2 > idx) m--;
   m = __builtin_amdgcn_readfirstlane(m);
   const int mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
-  if (nranks > 1 && (Tw / 4 + mc) % nranks != rank) return;
+  if (nranks > 0 && (Tw / 4 + mc) % nranks != rank) return;
   const int TR0 = Tw + 4 * m, TC0 = Tw + 4 * mc;
   const int last = nT - 2;  // last tile row / column of the square
   // (sharded: nobody else forms the next diagonal block's tiles -- its owner does, here)
-  const int Tx = nranks > 1 ? -4 : Tw;
+  const int Tx = nranks > 0 ? -4 : Tw;
   if (mc < m && TR0 + 3 <= last && (m > 0))
     wide4_block<true>(Lw, Lx, ld, J, KW, Tx, last, TR0, TC0, li, lk);
   else
@@ -883,7 +883,7 @@ static ChainShape chain_shape(const psba_ctx *h) {
 
 // one super-panel [J, J + NB) of the two-level chain: its 32-column steps, which update only the
 // super-panel's remaining columns (all rows below), then ONE K = NB update of everything to its
-// right.  nranks > 1: that update only for this rank's 64-column blocks (k_cholg_update_wide4).
+// right.  nranks > 0: that update only for this rank's 64-column blocks (k_cholg_update_wide4); 0: replicated.
 static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, int J, int nranks, int rank) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;
   double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
@@ -908,7 +908,7 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
   }
   if (JE < n32) {
     const int Tw = JE / 16;
-    if ((getenv("PSBA_CHOL_WIDE2") || (JE - J) % (2 * GB)) && nranks == 1) {  // the 2x2-tile kernel (any width; for comparison)
+    if ((getenv("PSBA_CHOL_WIDE2") || (JE - J) % (2 * GB)) && nranks == 0) {  // the 2x2-tile kernel (any width; for comparison)
       const long long MR = (nT - 1 - Tw) / 2;
       const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
       hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
@@ -974,7 +974,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   const bool fused = c.fused, blocked = c.blocked, fused2 = c.fused2;
   if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
-  for (int J = 0; blocked && J < n32; J += c.NB) enqueue_superpanel(h, s, c, J, 1, 0);
+  for (int J = 0; blocked && J < n32; J += c.NB) enqueue_superpanel(h, s, c, J, 0, 0);
   for (int j = 0; !blocked && j < n32; j += GB) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;
@@ -1077,13 +1077,14 @@ static int chol_dist_comm(psba_ctx *h) {
     for (int B = B0; B < B1; B++)
       if (B % h->nranks == h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 0);
     if (ncclGroupStart() != ncclSuccess) return fail(h, PSBA_E_RCCL, "ncclGroupStart failed");
-    for (int B = B0; B < B1; B++) {
+    bool sent = true;
+    for (int B = B0; B < B1 && sent; B++) {
       double *b = h->dist_buf + (size_t)(B - B0) * per;
       const size_t n = (size_t)(n32 + 1 - 64 * B) * (size_t)(n32 - 64 * B < 64 ? n32 - 64 * B : 64);
-      if (ncclBroadcast(b, b, n, ncclDouble, B % h->nranks, h->comm, h->stream) != ncclSuccess)
-        return fail(h, PSBA_E_RCCL, "ncclBroadcast failed in the column exchange");
+      sent = ncclBroadcast(b, b, n, ncclDouble, B % h->nranks, h->comm, h->stream) == ncclSuccess;
     }
-    if (ncclGroupEnd() != ncclSuccess) return fail(h, PSBA_E_RCCL, "ncclGroupEnd failed");
+    if (ncclGroupEnd() != ncclSuccess || !sent)  // (the group is closed before any error return)
+      return fail(h, PSBA_E_RCCL, "ncclBroadcast failed in the column exchange");
     for (int B = B0; B < B1 && rc == PSBA_OK; B++)
       if (B % h->nranks != h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 1);
   }
@@ -1092,7 +1093,9 @@ static int chol_dist_comm(psba_ctx *h) {
 }
 
 int launch_chol_graph(psba_ctx *h) {
-  if (h->comm && h->nranks > 1 && !getenv("PSBA_CHOL_REPLICATED")) {
+  // (PSBA_CHOL_DIST_FORCE=1: test hook -- a one-rank communicator takes the exchange path too, so that its
+  // pack / broadcast / unpack sequence runs on hardware that has a single GPU)
+  if (h->comm && (h->nranks > 1 || getenv("PSBA_CHOL_DIST_FORCE")) && !getenv("PSBA_CHOL_REPLICATED")) {
     int NB, blocked;
     chol_dist_shape(h, &NB, &blocked);
     if (blocked) {

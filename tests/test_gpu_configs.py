@@ -735,6 +735,34 @@ def test_single_rank_communicator_with_many_cameras(problems, monkeypatch, force
     h.close()
 
 
+def test_column_exchange_of_the_sharded_factorization_over_rccl(monkeypatch):
+    """The RCCL form of the sharded dense factorization (pack the owned 64-column blocks, grouped
+    ncclBroadcast per super-panel, unpack, factor the super-panel's first diagonal block afterwards) on the
+    one GPU there is: a one-rank communicator forced onto the exchange path (PSBA_CHOL_DIST_FORCE=1) must
+    give the replicated chain's solution.  (The multi-rank arithmetic is
+    test_sharded_dense_factorization_emulated_with_three_handles; N > 1 over xGMI is unmeasured.)"""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=460, n_pts=3000, mean_track=5.0, seed=993)
+    outs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("PSBA_CHOL_DIST_FORCE", "1")
+        h = psba_amd.Psba(0)
+        h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
+        h.upload_problem(prob)
+        n32, nb, sharded = h.chol_dist_shape()
+        assert sharded and nb % 64 == 0
+        h.linearize(1.0, 1.0)
+        mu = 1e-3 * h.max_diag()
+        h.schur_assemble(mu); h.schur_reduce(); h.schur_solve()
+        outs.append(h.get_dp()[: 6 * 460].copy())
+        sc = h.backsub(mu)
+        assert sc.status == 0
+        h.close()
+    assert np.abs(outs[1] - outs[0]).max() <= 1e-12 * np.abs(outs[0]).max()
+
+
 @pytest.mark.parametrize("name", ["7cams", "54cams", "trafalgar21"])
 def test_ring_route_opt_in(name, problems, monkeypatch):
     """K2's ring route (PSBA_SCHUR_RING=1: blocks of S owned by lanes, W records streamed into LDS by
