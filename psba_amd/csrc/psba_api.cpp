@@ -394,7 +394,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     // produce -- one byte per block of the lower triangle, combined with a max all-reduce over the
     // communicator, or handed in by a host that has its own transport (psba_set_sparse_pattern)
     std::vector<unsigned char> pat;
-    if (h->nranks > 1) {
+    // (PSBA_SPARSE_PATTERN_FORCE=1: test hook -- a one-rank communicator exchanges its pattern too)
+    if (h->nranks > 1 || (h->comm && getenv("PSBA_SPARSE_PATTERN_FORCE"))) {
       const size_t nBlk = (size_t)nCams * (nCams + 1) / 2;
       if (h->comm) {
         pat.resize(nBlk);

@@ -735,6 +735,31 @@ def test_single_rank_communicator_with_many_cameras(problems, monkeypatch, force
     h.close()
 
 
+def test_block_sparse_route_with_a_single_rank_communicator(monkeypatch):
+    """The RCCL calls of the block-sparse route on the one GPU there is: the max all-reduce of the block
+    pattern at upload (forced for one rank: PSBA_SPARSE_PATTERN_FORCE=1) and the per-try all-reduce of the
+    value array + e_a must leave the LM run of a handle without a communicator unchanged."""
+    import psba_amd
+    import psba_amd.synth as synth
+    prob = synth.make_problem(n_cams=300, n_pts=4000, mean_track=4.0, seed=995, window=30)
+    ref = psba_amd.Psba(0)
+    ref.set_solver(1, tol=1e-12, max_iter=2000)
+    ref.upload_problem(prob)
+    want, _ = ref.levmar(max_iter=4, tr_handoff=False)
+    nb_ref = ref.pcg_info()[2]
+    ref.close()
+    monkeypatch.setenv("PSBA_SPARSE_PATTERN_FORCE", "1")
+    h = psba_amd.Psba(0)
+    h.comm_init(1, 0, psba_amd.Psba.comm_unique_id())
+    h.set_solver(1, tol=1e-12, max_iter=2000)
+    h.upload_problem(prob)
+    assert h.schur_path() == 4 and h.pcg_info()[2] == nb_ref
+    res, _ = h.levmar(max_iter=4, tr_handoff=False)
+    assert res.iters == want.iters
+    assert abs(res.final_err - want.final_err) <= 1e-10 * want.final_err
+    h.close()
+
+
 def test_column_exchange_of_the_sharded_factorization_over_rccl(monkeypatch):
     """The RCCL form of the sharded dense factorization (pack the owned 64-column blocks, grouped
     ncclBroadcast per super-panel, unpack, factor the super-panel's first diagonal block afterwards) on the
