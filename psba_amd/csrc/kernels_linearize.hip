@@ -28,6 +28,11 @@ struct LinArgs {
   double coeff, coeff_g;
   int nC, nTiles;
   int mode;  // development ablation (PSBA_LIN_MODE): 1 no camera atomics, 2 no W store, 3 no per-point sums
+  // the linearization queued ahead of the host's verdict carries the previous kernel's (K3's) scalar
+  // block to the host: workgroup 0 copies pub_src[0 .. NSCAL) to pinned host memory, then the stamp
+  const double *pub_src;
+  double *pub_dst;  // nullptr: nothing to publish
+  double pub_stamp;
 };
 
 // GACC: many cameras -- the 27 sums per camera do not fit the LDS.  They are then formed by a
@@ -38,6 +43,13 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   __shared__ double sW[(TILE_OBS / 2) * 19];  // W blocks of half a tile (staged in two halves: LDS for three workgroups per CU)
   extern __shared__ double sAcc[];     // [nC][27]
   const int tid = threadIdx.x;
+  if (p.pub_dst && blockIdx.x == 0) {
+    // (a kernel of its own for these 832 bytes sat 4 us on the stream between K3 and this kernel)
+    if (tid < NSCAL) p.pub_dst[tid] = p.pub_src[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) p.pub_dst[NSCAL] = p.pub_stamp;
+  }
   const int nAcc = GACC ? 0 : p.nC * CAM_ACC;
   for (int t = tid; t < nAcc; t += TILE_OBS) sAcc[t] = 0.0;
   __syncthreads();
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256) void k_max_diag(const double *U, const double 
   }
 }
 
-int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
+int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
   const Dims &d = h->d;
   LinArgs a;
   a.camconst = h->camconst;
@@ -430,6 +442,9 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead) {
   a.coeff_g = h->coeff_g;
   a.nC = d.nC;
   a.nTiles = d.nTiles;
+  a.pub_src = h->scal;
+  a.pub_dst = publish ? h->h_scal_dev : nullptr;
+  a.pub_stamp = h->pub_seq;
   {
     const char *m = getenv("PSBA_LIN_MODE");
     a.mode = m ? atoi(m) : 0;

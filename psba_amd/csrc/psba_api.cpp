@@ -198,7 +198,7 @@ int psba_create(int device, psba_handle *out) {
   if ((e = hipSetDevice(device)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipMalloc((void **)&h->scal, sizeof(double) * NSCAL)) != hipSuccess ||
-      (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * NSCAL)) != hipSuccess ||
+      (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * (NSCAL + 8))) != hipSuccess ||  // (+ the publish stamp)
       (e = hipEventCreateWithFlags(&h->scal_event, hipEventDisableTiming)) != hipSuccess) {
     int rc = fail(nullptr, PSBA_E_HIP, "psba_create: %s", hipGetErrorString(e));
     delete h;
@@ -209,6 +209,7 @@ int psba_create(int device, psba_handle *out) {
   h->status = reinterpret_cast<int *>(h->scal + 8);
   h->h_status = reinterpret_cast<int *>(h->h_scal + 8);
   (void)hipMemset(h->scal, 0, sizeof(double) * NSCAL);
+  h->h_scal[NSCAL] = 0.0;  // the publish stamp (psba_backsub_wait)
   *out = h;
   return PSBA_OK;
 }
@@ -576,7 +577,7 @@ int psba_set_params(psba_handle h, const double *camsEx, const double *pts3D) {
                              hipMemcpyHostToDevice, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));
   h->linearized = h->assembled = h->solved = h->backsubbed = false;
-  h->ahead = h->lin_is_ahead = h->backsub_pending = false;
+  h->ahead = h->lin_is_ahead = h->backsub_pending = h->publish_deferred = h->publish_in_k1 = false;
   return PSBA_OK;
 }
 
@@ -588,7 +589,7 @@ int psba_reset_params(psba_handle h) {
   PSBA_HIP(h, hipMemcpyAsync(h->pts[h->cur], h->params0 + h->d.nA, sizeof(double) * h->d.nB,
                              hipMemcpyDeviceToDevice, h->stream));
   h->linearized = h->assembled = h->solved = h->backsubbed = false;
-  h->ahead = h->lin_is_ahead = h->backsub_pending = false;
+  h->ahead = h->lin_is_ahead = h->backsub_pending = h->publish_deferred = h->publish_in_k1 = false;
   return PSBA_OK;
 }
 
@@ -759,6 +760,16 @@ int psba_schur_solve(psba_handle h) {
   return PSBA_OK;
 }
 
+// the try's scalar block to the host behind everything queued on s, and the event the host waits for
+static int publish_scalars(psba_ctx *h, hipStream_t s) {
+  if (h->h_scal_dev && !getenv("PSBA_SCAL_MEMCPY"))
+    TRY(launch_publish_scal(h, s));
+  else
+    PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, s));
+  PSBA_HIP(h, hipEventRecord(h->scal_event, s));
+  return PSBA_OK;
+}
+
 int psba_backsub_async(psba_handle h, double mu) {
   CHECK_H(h);
   NEED(h, h->solved, "psba_schur_solve first");
@@ -782,11 +793,12 @@ int psba_backsub_async(psba_handle h, double mu) {
     }
     RCCL(h, ncclAllReduce(h->scal + SC_PART, h->scal + SC_PART, 4 * SC_NPART + 2, ncclDouble, ncclSum, h->comm, s));
   }
-  if (h->h_scal_dev && !getenv("PSBA_SCAL_MEMCPY"))
-    TRY(launch_publish_scal(h, s));
-  else
-    PSBA_HIP(h, hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, s));
-  PSBA_HIP(h, hipEventRecord(h->scal_event, s));
+  h->publish_in_k1 = false;
+  // single rank: the scalars are not sent yet -- if psba_linearize_ahead comes next, its kernel carries
+  // them (no kernel of their own between K3 and the linearization); psba_backsub_wait sends them
+  // itself otherwise
+  h->publish_deferred = !h->comm && h->h_scal_dev && !getenv("PSBA_SCAL_MEMCPY") && !getenv("PSBA_SCAL_KERNEL");
+  if (!h->publish_deferred) TRY(publish_scalars(h, s));
   h->solved = false;  // the try's accumulators are consumed; a new try starts at psba_schur_assemble
   h->backsub_pending = true;
   h->ahead = false;
@@ -796,7 +808,13 @@ int psba_backsub_async(psba_handle h, double mu) {
 int psba_linearize_ahead(psba_handle h) {
   CHECK_H_NOJOIN(h);  // K1 reads and writes nothing the scalar collective touches
   NEED(h, h->backsub_pending || h->backsubbed, "psba_backsub_async / psba_backsub first");
-  TRY(launch_linearize(h, false, true));
+  const bool carry = h->backsub_pending && h->publish_deferred;
+  if (carry) h->pub_seq += 1.0;
+  TRY(launch_linearize(h, false, true, carry));
+  if (carry) {
+    h->publish_deferred = false;
+    h->publish_in_k1 = true;
+  }
   h->ahead = true;
   return PSBA_OK;
 }
@@ -804,11 +822,32 @@ int psba_linearize_ahead(psba_handle h) {
 int psba_backsub_wait(psba_handle h, psba_try_scalars *out) {
   CHECK_H_NOJOIN(h);
   NEED(h, h->backsub_pending, "psba_backsub_async first");
-  // a try is ~180 us of GPU work: poll the event for a while before handing the thread to the
-  // runtime's wait (0.9 us per LM iteration on the venice-shaped problem)
-  for (int spin = 0; spin < 20000 && hipEventQuery(h->scal_event) == hipErrorNotReady; spin++) {
+  if (h->publish_deferred) {  // no linearization was queued ahead: send the scalars now
+    TRY(publish_scalars(h, h->stream));
+    h->publish_deferred = false;
   }
-  PSBA_HIP(h, hipEventSynchronize(h->scal_event));
+  if (h->publish_in_k1) {
+    // workgroup 0 of the linearization queued ahead writes the block and then the stamp: poll the
+    // stamp in pinned memory (a try is ~180 us of GPU work); should it not arrive, the stream's end
+    // tells why
+    volatile double *stamp = h->h_scal + NSCAL;
+    long long spin = 0;
+    while (*stamp != h->pub_seq && ++spin < 200000000LL) {
+      if ((spin & 0xfffff) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+    }
+    if (*stamp != h->pub_seq) {
+      PSBA_HIP(h, hipStreamSynchronize(h->stream));
+      if (*stamp != h->pub_seq) return fail(h, PSBA_E_HIP, "the try's scalars did not reach the host");
+    }
+    __sync_synchronize();
+    h->publish_in_k1 = false;
+  } else {
+    // poll the event for a while before handing the thread to the runtime's wait (0.9 us per LM
+    // iteration on the venice-shaped problem)
+    for (int spin = 0; spin < 20000 && hipEventQuery(h->scal_event) == hipErrorNotReady; spin++) {
+    }
+    PSBA_HIP(h, hipEventSynchronize(h->scal_event));
+  }
   h->scal_side = false;  // the host has seen the side stream's work complete
   h->backsub_pending = false;
   // the four sums arrive as SC_NPART partial sets: add them up in a fixed order

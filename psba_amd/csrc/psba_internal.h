@@ -270,6 +270,12 @@ struct psba_ctx {
   // ---- state ----
   bool uploaded = false, linearized = false, assembled = false, solved = false, backsubbed = false;
   bool backsub_pending = false;  // psba_backsub_async issued, psba_backsub_wait not yet
+  // the try's scalars travel to the host with the linearization queued ahead (its workgroup 0 copies
+  // them and then writes a stamp the host polls) instead of through a kernel of their own between K3
+  // and that linearization: publish_deferred = K3 queued, nothing published yet; publish_in_k1 = the
+  // queued K1 carries them, the host waits for pub_seq in h_scal[NSCAL]
+  bool publish_deferred = false, publish_in_k1 = false;
+  double pub_seq = 0.0;
   int cur = 0;                  // index of the current parameter set in cams[]/pts[]
   double coeff = 1.0, coeff_g = 1.0, mu = 0.0;
   double coeff_w = 1.0;         // the coefficient the stored W was formed with (last K1 launch)
@@ -305,7 +311,7 @@ struct ProfScope {
 
 // ---- kernel launchers (one per .hip file) ----
 // kernels_linearize.hip
-int launch_linearize(psba_ctx *h, bool dump, bool ahead = false);
+int launch_linearize(psba_ctx *h, bool dump, bool ahead = false, bool publish = false);
 int launch_residual(psba_ctx *h, int which, double *ex_out_dev);
 int launch_max_diag(psba_ctx *h);
 // kernels_schur.hip
