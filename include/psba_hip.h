@@ -391,6 +391,22 @@ int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long lo
                          int *blockpos, int *glo);
 void psba_schur_plan_destroy(psba_schur_plan_t p);
 
+/* ---- test hook: the product lists of the owner route (K2 for >= 2048 cameras, for points seen by more
+ * cameras than a tile holds, and for the block-sparse S), built on the host only.  Every product
+ * Y_a W_b^T belongs to the block (camera of a, camera of b) of the lower block triangle; a thread owns a
+ * unit = (block, segment of its products), 64 units to a wave, a wave's products in ELL rows.
+ * info[0..3] = waves, ELL rows, products, blocks in the block list.
+ * psba_owner_plan_copy: waves[waves][2] = first ELL row, rows; units[64 waves][4] = j, k, multi (the block
+ * has several units), slot in the block list (-1: idle lane); prod[64 rows][2] = observations (a, b), a = -1
+ * padding; blocks[blocks][2] = (j, k) in canonical order; diag_slot[nCams].  pattern (may be NULL): the
+ * union pattern of psba_sparse_pattern -- blocks flagged there exist even without a product here. */
+typedef struct psba_owner_plan *psba_owner_plan_t;
+psba_owner_plan_t psba_owner_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, const int *jidx,
+                                         const unsigned char *pattern);
+int psba_owner_plan_info(psba_owner_plan_t p, long long info[4]);
+int psba_owner_plan_copy(psba_owner_plan_t p, long long *waves, int *units, int *prod, int *blocks, int *diag_slot);
+void psba_owner_plan_destroy(psba_owner_plan_t p);
+
 /* ---- test hook: the schedule of the S-assembly kernel's ring route (few cameras), host only ----
  * The lower block triangle of S (reference CL_files/compute_S.cl:6-78) is cut into nR ranges of the
  * canonical block order and the point sequence into nS stretches; a workgroup per (range, stretch)

@@ -148,6 +148,10 @@ SIGNATURES = [
     ("psba_schur_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_schur_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_longlong), _ip, _ip]),
     ("psba_schur_plan_destroy", None, [C.c_void_p]),
+    ("psba_owner_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
+    ("psba_owner_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    ("psba_owner_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _ip, _ip, _ip, _ip]),
+    ("psba_owner_plan_destroy", None, [C.c_void_p]),
     ("psba_ring_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("psba_ring_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_ring_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _ip, C.POINTER(C.c_uint), _ip, _ip, _ip, _ip, _ip]),
@@ -263,6 +267,31 @@ def schur_plan(n_cams, n_pts, iidx, jidx):
         lib.psba_schur_plan_destroy(p)
     return dict(groups=groups, items=items, wg=wg, blockpos=blockpos, glo=glo, products=products,
                 slab_doubles=slab)
+
+
+def owner_plan(n_cams, n_pts, iidx, jidx, pattern=None):
+    """The product lists of the owner route for a sparsity pattern (host only, no device): dict of the
+    arrays psba_owner_plan_copy documents."""
+    iidx = _c(iidx, np.int32)
+    jidx = _c(jidx, np.int32)
+    pat = None if pattern is None else np.ascontiguousarray(pattern, dtype=np.uint8)
+    pp = None if pat is None else pat.ctypes.data_as(C.POINTER(C.c_ubyte))
+    p = lib.psba_owner_plan_create(int(n_cams), int(n_pts), int(iidx.size), _i(iidx), _i(jidx), pp)
+    if not p:
+        raise PsbaError(-1, "psba_owner_plan_create failed")
+    try:
+        info = (C.c_longlong * 4)()
+        lib.psba_owner_plan_info(p, info)
+        nw, rows, products, nblk = (int(x) for x in info)
+        waves = np.zeros((nw, 2), dtype=np.int64)
+        units = np.zeros((64 * nw, 4), dtype=np.int32)
+        prod = np.zeros((64 * rows, 2), dtype=np.int32)
+        blocks = np.zeros((nblk, 2), dtype=np.int32)
+        diag = np.zeros(int(n_cams), dtype=np.int32)
+        lib.psba_owner_plan_copy(p, waves.ctypes.data_as(C.POINTER(C.c_longlong)), _i(units), _i(prod), _i(blocks), _i(diag))
+    finally:
+        lib.psba_owner_plan_destroy(p)
+    return dict(waves=waves, units=units, prod=prod.reshape(rows, 64, 2), blocks=blocks, diag_slot=diag, products=products)
 
 
 def ring_plan(n_cams, n_pts, iidx, jidx):

@@ -1563,6 +1563,69 @@ int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long lo
 
 void psba_schur_plan_destroy(psba_schur_plan_t p) { delete p; }
 
+// ---- test hook: the owner route's product lists (many cameras, long tracks, block-sparse S), host only ----
+struct psba_owner_plan {
+  psba::OwnerPlanHost plan;
+};
+
+psba_owner_plan_t psba_owner_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, const int *jidx,
+                                         const unsigned char *pattern) {
+  if (nCams <= 0 || n3Dpts <= 0 || n2Dprojs <= 0 || !iidx || !jidx) return nullptr;
+  std::vector<int> ptr((size_t)n3Dpts + 1, 0);
+  for (int a = 0; a < n2Dprojs; a++) {
+    if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return nullptr;
+    if (a && iidx[a] < iidx[a - 1]) return nullptr;  // point-major, as psba_upload_problem requires
+    ptr[(size_t)iidx[a] + 1]++;
+  }
+  for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[i];
+  psba_owner_plan *p = new (std::nothrow) psba_owner_plan;
+  if (!p) return nullptr;
+  if (psba::build_owner_plan(nCams, n2Dprojs, iidx, jidx, ptr.data(), p->plan, pattern) != PSBA_OK) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+int psba_owner_plan_info(psba_owner_plan_t p, long long info[4]) {
+  if (!p || !info) return PSBA_E_INVALID;
+  info[0] = (long long)p->plan.waves.size();
+  info[1] = (long long)p->plan.prod.size() / 64;  // ELL rows
+  info[2] = p->plan.products;
+  info[3] = (long long)p->plan.blocks.size();
+  return PSBA_OK;
+}
+
+int psba_owner_plan_copy(psba_owner_plan_t p, long long *waves, int *units, int *prod, int *blocks, int *diag_slot) {
+  if (!p) return PSBA_E_INVALID;
+  if (waves)
+    for (size_t w = 0; w < p->plan.waves.size(); w++) {
+      waves[2 * w] = p->plan.waves[w].row0;
+      waves[2 * w + 1] = p->plan.waves[w].len;
+    }
+  if (units)
+    for (size_t u = 0; u < p->plan.units.size(); u++) {
+      units[4 * u] = p->plan.units[u].j;
+      units[4 * u + 1] = p->plan.units[u].k;
+      units[4 * u + 2] = p->plan.units[u].multi;
+      units[4 * u + 3] = p->plan.units[u].slot;
+    }
+  if (prod)
+    for (size_t t = 0; t < p->plan.prod.size(); t++) {
+      prod[2 * t] = p->plan.prod[t].x;
+      prod[2 * t + 1] = p->plan.prod[t].y;
+    }
+  if (blocks)
+    for (size_t b = 0; b < p->plan.blocks.size(); b++) {
+      blocks[2 * b] = p->plan.blocks[b].x;
+      blocks[2 * b + 1] = p->plan.blocks[b].y;
+    }
+  if (diag_slot) std::copy(p->plan.diag_slot.begin(), p->plan.diag_slot.end(), diag_slot);
+  return PSBA_OK;
+}
+
+void psba_owner_plan_destroy(psba_owner_plan_t p) { delete p; }
+
 // ---- test hook: the ring route's schedule (schur_ring_plan.cpp), host only ----
 struct psba_ring_plan {
   psba::RingPlanHost plan;

@@ -364,3 +364,55 @@ def test_sparse_pattern_is_the_covisibility_of_camera_pairs():
             assert bool(flags[j * (j + 1) // 2 + k]) == bool(want[j, k]), (j, k)
     parts = [capi.sparse_pattern(capi.shard_problem(prob, 3, r)) for r in range(3)]
     assert np.array_equal(np.maximum.reduce(parts), flags)
+
+
+@pytest.mark.parametrize("n_cams,window", [(40, None), (300, 25)])
+def test_owner_plan_lists_every_product_once(n_cams, window):
+    """The owner route's static plan (schur_plan.cpp build_owner_plan; K2 for >= 2048 cameras, long tracks
+    and the block-sparse S), replayed on the host: every product (a, b) of a point's observations, b <= a,
+    sits in exactly one unit of the block (camera of a, camera of b); a block with several units is
+    marked for atomic adds; the block list is the co-visible camera pairs plus every diagonal block in
+    canonical order, and with a union pattern handed in (sharded points) the flagged blocks exist too."""
+    from psba_amd import capi, synth
+    prob = synth.make_problem(n_cams=n_cams, n_pts=500, mean_track=4.0, seed=31 + n_cams, window=window)
+    ii, jj = prob["iidx"], prob["jidx"]
+    pl = capi.owner_plan(prob["nC"], prob["nP"], ii, jj)
+    want = {}
+    start = 0
+    for a in range(prob["nO"]):
+        if a and ii[a] != ii[a - 1]:
+            start = a
+        for b in range(start, a + 1):
+            want[(a, b)] = (int(jj[a]), int(jj[b]))
+    assert pl["products"] == len(want)
+    blocks = [tuple(x) for x in pl["blocks"]]
+    assert blocks == sorted(blocks)  # canonical order: by j, then k
+    present = set(want.values()) | {(j, j) for j in range(n_cams)}
+    assert set(blocks) == present
+    assert all(blocks[pl["diag_slot"][j]] == (j, j) for j in range(n_cams))
+    seen = {}
+    units_of_block = {}
+    for w, (row0, ln) in enumerate(pl["waves"]):
+        for lane in range(64):
+            j, k, multi, slot = pl["units"][64 * w + lane]
+            if slot < 0:
+                continue
+            assert blocks[slot] == (j, k)
+            units_of_block.setdefault((j, k), []).append(multi)
+            for t in range(ln):
+                a, b = pl["prod"][row0 + t, lane]
+                if a < 0:
+                    continue
+                assert want[(int(a), int(b))] == (j, k)
+                assert (int(a), int(b)) not in seen
+                seen[(int(a), int(b))] = 1
+    assert len(seen) == len(want)
+    for blk, ms in units_of_block.items():
+        assert all(m == (1 if len(ms) > 1 else 0) for m in ms), blk
+    # sharded points: a pattern with extra blocks puts them into the list (they stay empty here)
+    pat = capi.sparse_pattern(prob).copy()
+    extra = [(j, k) for j in range(n_cams) for k in range(j) if (j, k) not in present][:5]
+    for j, k in extra:
+        pat[j * (j + 1) // 2 + k] = 1
+    pl2 = capi.owner_plan(prob["nC"], prob["nP"], ii, jj, pattern=pat)
+    assert set(tuple(x) for x in pl2["blocks"]) == present | set(extra)
