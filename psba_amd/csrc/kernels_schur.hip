@@ -214,7 +214,10 @@ struct SchurLdsArgs {
 // 1 = products without the LDS atomics; 2 = no product loop; 3 = no W_b loads (wrong
 // results); 4 = zero + flush only; 5 = every row of 16 lanes on 16 distinct bank pairs by
 // construction (wrong results: what the bank conflicts of the real schedule cost); 6 = the 36
-// atomics without the 108 fp64 operations that form the values.
+// atomics without the 108 fp64 operations that form the values; 7 = ds_add_u64 on the values' bit
+// patterns; 8 = 6 with ds_add_u64; 9 = all loads and arithmetic, no LDS atomics; 10 / 11 = all loads,
+// V*^-1 only, 36 f64 / u64 atomics of loaded values; 12 / 13 = no record loads, arithmetic + f64 / u64
+// atomics; 14 = one a-side and two partners per turn (all of 7..14 give wrong sums).
 template <bool DUMP, int MODE>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   extern __shared__ double sPart[];  // [nblk][37]
@@ -230,9 +233,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   // the next item word is fetched a turn ahead: its latency would otherwise sit in front of the
   // record loads of every turn (a wave has only about six turns)
   unsigned long long item_next = (wg.item0 + tid < s1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
-  for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
+  constexpr int STEP = (MODE == 14 ? 2 : 1) * SCHUR_THREADS;
+  for (long long t = wg.item0 + tid; t < s1; t += STEP) {
     const unsigned long long item = item_next;
-    if (t + SCHUR_THREADS < s1) item_next = p.items[t + SCHUR_THREADS];
+    if (t + STEP < s1) item_next = p.items[t + STEP];
+    // MODE 14 (timing only, wrong sums): what an item with one a-side and two partners would cost --
+    // the turn's second product takes its partner and its block from the item 1024 further on and
+    // reuses this item's W_a, V*^-1, Y, e
+    unsigned long long item2 = SCHUR_NULL_ITEM;
+    if (MODE == 14 && t + SCHUR_THREADS < s1) item2 = p.items[t + SCHUR_THREADS];
     if (item == SCHUR_NULL_ITEM) continue;
     const int a = wg.obs0 + (int)(item & ((1u << ITEM_OBS_BITS) - 1));
     const int i = wg.pt0 + (int)((item >> ITEM_OBS_BITS) & ((1u << ITEM_PT_BITS) - 1));
@@ -363,6 +372,38 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
           atomicAdd(reinterpret_cast<unsigned long long *>(&blk[6 * r + c]), (unsigned long long)__double_as_longlong(val[c]));
         else
           atomicAdd(&blk[6 * r + c], val[c]);
+      }
+    }
+    if (MODE == 14 && item2 != SCHUR_NULL_ITEM) {
+      const int boffB = (int)((item2 >> (ITEM_OBS_BITS + ITEM_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
+      const int posB = (int)(item2 >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
+      const int bB = a - boffB > wg.obs0 ? a - boffB : wg.obs0;
+      const double2 *wq = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)bB);
+      double wc[18];
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double2 q = wq[k];
+        wc[2 * k] = q.x;
+        wc[2 * k + 1] = q.y;
+      }
+      double *blkB = sPart + BLK_STRIDE * posB;
+      const bool selfB = boffB == 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        double val[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) val[c] = Y[3 * r] * wc[3 * c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 1], wc[3 * c + 1], val[c]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 2], wc[3 * c + 2], val[c]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          if (r == 0 && c >= 1) val[c] = selfB ? e[c - 1] : val[c];
+          if (r == 1 && c == 2) val[c] = selfB ? e[5] : val[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) atomicAdd(&blkB[6 * r + c], val[c]);
       }
     }
   }
@@ -757,6 +798,8 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
         hipLaunchKernelGGL((k_schur_lds<false, 12>), G, B, lds, h->stream, a);
       else if (mode == 13)
         hipLaunchKernelGGL((k_schur_lds<false, 13>), G, B, lds, h->stream, a);
+      else if (mode == 14)
+        hipLaunchKernelGGL((k_schur_lds<false, 14>), G, B, lds, h->stream, a);
       else
         hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
     }
