@@ -19,7 +19,12 @@
 namespace psba {
 
 // slots of the PCG scalar block (doubles, device)
-enum { PC_RZ = 0, PC_PQ = 1, PC_RZ_NEW = 2, PC_RR = 3, PC_BB = 4, PC_FAIL = 5, PC_N = 8 };
+// p.Sp, r.r and r.z of iteration `it` live in slot it % 4 (r.z of the next iteration accumulates in slot
+// (it + 1) % 4); the last kernel of an iteration zeroes the slots two iterations ahead, so no slot is
+// ever zeroed while a kernel in flight reads or adds to it, and nothing has to be rolled over
+// (p.Sp is added up by thousands of workgroups: it goes into 64 partial sums per slot, PC_PQ + 64 slot + k,
+// because same-address atomics serialise at ~13 ns each -- 1800 of them were 24 us per iteration)
+enum { PC_BB = 0, PC_FAIL = 1, PC_RR = 4, PC_RZ = 8, PC_N = 16, PC_PQ = 16, PC_NPQ = 64, PC_ALL = 16 + 4 * 64 };
 
 // diagonal blocks += U_j + mu I (rank 0 adds mu), e_a += g_a, the try's accumulators of K3 zeroed
 __global__ __launch_bounds__(256) void k_bsr_finalize(double *val, const int *diag_slot, double *ea, const double *U,
@@ -102,34 +107,6 @@ __global__ __launch_bounds__(64) void k_bsr_diag_inverse(const double *val, cons
   }
 }
 
-// y += S x for the blocks of the lower block triangle: block (j, k) gives y_j += B x_k and, off the
-// diagonal, y_k += B^T x_j.  Six lanes per block (one output row each), fp64 atomics into y (zeroed
-// before).  A diagonal block is read through its lower triangle (see k_bsr_diag_inverse).
-__global__ __launch_bounds__(256) void k_bsr_spmv(const double *val, const int2 *jk, long long nb, const double *x,
-                                                  double *y) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long b = t / 6;
-  const int r = (int)(t % 6);
-  if (b >= nb) return;
-  const int2 q = jk[b];
-  const double *B = val + 36 * (size_t)b;
-  const double *xk = x + 6 * (size_t)q.y, *xj = x + 6 * (size_t)q.x;
-  double s = 0.0, tt = 0.0;
-  if (q.x == q.y) {
-#pragma unroll
-    for (int c = 0; c < 6; c++) s += (c <= r ? B[6 * r + c] : B[6 * c + r]) * xk[c];
-    atomicAdd(&y[6 * (size_t)q.x + r], s);
-    return;
-  }
-#pragma unroll
-  for (int c = 0; c < 6; c++) {
-    s += B[6 * r + c] * xk[c];
-    tt += B[6 * c + r] * xj[c];
-  }
-  atomicAdd(&y[6 * (size_t)q.x + r], s);
-  atomicAdd(&y[6 * (size_t)q.y + r], tt);
-}
-
 __device__ __forceinline__ void block_sum_to(double v, double *dst) {
   __shared__ double sRed[4];
 #pragma unroll
@@ -137,9 +114,54 @@ __device__ __forceinline__ void block_sum_to(double v, double *dst) {
   if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(dst, sRed[0] + sRed[1] + sRed[2] + sRed[3]);
+  __syncthreads();
 }
 
-// start: x = 0, r = b, z = M^-1 r, p = z, rz = r.z, bb = b.b; one thread per unknown
+// q = S p and p.q with it, without atomics into q: one wave per block row j walks the row of the full
+// symmetric pattern (bs_rowent: a stored block of the lower triangle serves its row as stored and its
+// column's row transposed; a diagonal block is read through its lower triangle, see
+// k_bsr_diag_inverse).  Lane = 6 g + r: eight entries at a time, one output row each; the eight partial
+// sums of a row are added up by shuffles.  (The first version walked the stored blocks, six lanes each,
+// with two fp64 atomics into q per lane: 2.2 M scattered atomics per product at 186 k blocks.)
+__global__ __launch_bounds__(256) void k_pcg_spmv(const double *val, const int *rowptr, const int2 *rowent, int nC,
+                                                  const double *p, double *q, double *pc, int it) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double acc = 0.0;
+  const int g = lane / 6, r = lane % 6;
+  if (j < nC && g < 8) {
+    const int e1 = rowptr[j + 1];
+    for (int e = rowptr[j] + g; e < e1; e += 8) {
+      const int2 en = rowent[e];
+      const int how = en.y >> 28, o = en.y & 0x0fffffff;
+      const double *B = val + 36 * (size_t)en.x;
+      const double *xo = p + 6 * (size_t)o;
+      double s = 0.0;
+      if (how == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += B[6 * r + c] * xo[c];
+      } else if (how == 1) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += B[6 * c + r] * xo[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += (c <= r ? B[6 * r + c] : B[6 * c + r]) * xo[c];
+      }
+      acc += s;
+    }
+  }
+  acc += __shfl_down(acc, 24, 64);
+  acc += __shfl_down(acc, 12, 64);
+  acc += __shfl_down(acc, 6, 64);
+  double pq = 0.0;
+  if (j < nC && lane < 6) {
+    q[6 * (size_t)j + lane] = acc;
+    pq = p[6 * (size_t)j + lane] * acc;
+  }
+  block_sum_to(pq, pc + PC_PQ + PC_NPQ * (it & 3) + (blockIdx.x & (PC_NPQ - 1)));
+}
+
+// start: x = 0, r = b, z = M^-1 r, p = z, q = 0, r.z into slot 0, b.b; one thread per unknown
 __global__ __launch_bounds__(256) void k_pcg_start(const double *b, const double *minv, double *x, double *r, double *z,
                                                    double *p, double *q, int n, double *pc) {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -161,20 +183,26 @@ __global__ __launch_bounds__(256) void k_pcg_start(const double *b, const double
     bb = bt * bt;
   }
   block_sum_to(rz, pc + PC_RZ);
-  __syncthreads();
   block_sum_to(bb, pc + PC_BB);
 }
 
-__global__ __launch_bounds__(256) void k_pcg_dot(const double *a, const double *b, int n, double *dst) {
+// x += alpha p, r -= alpha q with alpha = r.z / p.Sp; then z = M^-1 r with the camera's 6x6 block: a
+// thread forms the new residual of all six rows of its camera itself (they are neighbours' rows, read
+// from r and q before anybody overwrites them: r and z are written to, r_new is not read back), so the
+// update and the preconditioner are one pass; r.r and the next r.z with it
+__global__ __launch_bounds__(256) void k_pcg_update(double *x, const double *r, double *rn, const double *p, const double *q,
+                                                    const double *minv, double *z, int n, double *pc, int it, int *status,
+                                                    int try_id) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  block_sum_to(t < n ? a[t] * b[t] : 0.0, dst);
-}
-
-// x += alpha p, r -= alpha q with alpha = rz / pq; rr = r.r; (q is zeroed for the next product)
-__global__ __launch_bounds__(256) void k_pcg_step1(double *x, double *r, const double *p, double *q, int n, double *pc,
-                                                   int *status, int try_id) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const double pq = pc[PC_PQ], rz = pc[PC_RZ];
+  __shared__ double sPq;
+  if (threadIdx.x < 64) {  // the 64 partial sums of p.Sp
+    double v = pc[PC_PQ + PC_NPQ * (it & 3) + threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) sPq = v;
+  }
+  __syncthreads();
+  const double pq = sPq, rz = pc[PC_RZ + (it & 3)];
   if (!(pq > 0.0)) {  // not positive definite (or a break-down): the LM loop raises mu
     if (t == 0) {
       status[1] = try_id;
@@ -183,48 +211,38 @@ __global__ __launch_bounds__(256) void k_pcg_step1(double *x, double *r, const d
     return;
   }
   const double alpha = rz / pq;
-  double rr = 0.0;
+  double rr = 0.0, rzn = 0.0;
   if (t < n) {
-    x[t] += alpha * p[t];
-    const double rt = r[t] - alpha * q[t];
-    r[t] = rt;
-    q[t] = 0.0;
-    rr = rt * rt;
-  }
-  block_sum_to(rr, pc + PC_RR);
-}
-
-// z = M^-1 r, rz_new = r.z
-__global__ __launch_bounds__(256) void k_pcg_precond(const double *r, const double *minv, double *z, int n, double *pc) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  double rz = 0.0;
-  if (t < n) {
-    const int j = t / 6, rr = t % 6;
-    const double *m = minv + 36 * (size_t)j + 6 * rr;
-    const double *rj = r + 6 * (size_t)j;
-    double zz = 0.0;
+    const int j = t / 6, row = t % 6;
+    const double *m = minv + 36 * (size_t)j + 6 * row;
+    double zz = 0.0, own = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; c++) zz += m[c] * rj[c];
+    for (int c = 0; c < 6; c++) {
+      const double rc = r[6 * (size_t)j + c] - alpha * q[6 * (size_t)j + c];
+      zz += m[c] * rc;
+      own = c == row ? rc : own;
+    }
+    x[t] += alpha * p[t];
+    rn[t] = own;
     z[t] = zz;
-    rz = r[t] * zz;
+    rr = own * own;
+    rzn = own * zz;
   }
-  block_sum_to(rz, pc + PC_RZ_NEW);
+  block_sum_to(rr, pc + PC_RR + (it & 3));
+  block_sum_to(rzn, pc + PC_RZ + ((it + 1) & 3));
 }
 
-// p = z + beta p with beta = rz_new / rz; then the scalars roll over (by block 0, after everybody has read them:
-// the roll-over is a kernel of its own below)
-__global__ __launch_bounds__(256) void k_pcg_step2(const double *z, double *p, int n, const double *pc) {
+// p = z + beta p with beta = r.z_new / r.z; the accumulators of the iteration after next zeroed
+__global__ __launch_bounds__(256) void k_pcg_direction(const double *z, double *p, int n, double *pc, int it) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < PC_NPQ) pc[PC_PQ + PC_NPQ * ((it + 2) & 3) + t] = 0.0;
+  if (t == 0) {
+    pc[PC_RR + ((it + 2) & 3)] = 0.0;
+    pc[PC_RZ + ((it + 3) & 3)] = 0.0;
+  }
   if (t >= n) return;
-  const double beta = pc[PC_RZ_NEW] / pc[PC_RZ];
+  const double beta = pc[PC_RZ + ((it + 1) & 3)] / pc[PC_RZ + (it & 3)];
   p[t] = z[t] + beta * p[t];
-}
-
-__global__ void k_pcg_roll(double *pc) {
-  pc[PC_RZ] = pc[PC_RZ_NEW];
-  pc[PC_RZ_NEW] = 0.0;
-  pc[PC_PQ] = 0.0;
-  pc[PC_RR] = 0.0;
 }
 
 int launch_bsr_finalize(psba_ctx *h, double mu) {
@@ -239,36 +257,40 @@ int launch_bsr_finalize(psba_ctx *h, double mu) {
 int launch_pcg_solve(psba_ctx *h) {
   const int n = h->d.nA, nC = h->d.nC, g = (n + 255) / 256;
   hipStream_t s = h->stream;
-  double *x = h->dp, *r = h->pcg_vec, *z = r + n, *p = z + n, *q = p + n, *pc = h->pcg_scal;
+  // r is kept in two buffers used in turn: an iteration's update reads the old residual of a whole
+  // camera (six rows) while other threads write the new one
+  double *x = h->dp, *r0 = h->pcg_vec, *z = r0 + n, *p = z + n, *q = p + n, *r1 = q + n, *pc = h->pcg_scal;
   ProfScope ps(h, PSBA_K_CHOLESKY);
-  PSBA_HIP(h, hipMemsetAsync(pc, 0, sizeof(double) * PC_N, s));
+  PSBA_HIP(h, hipMemsetAsync(pc, 0, sizeof(double) * PC_ALL, s));
   hipLaunchKernelGGL(k_bsr_diag_inverse, dim3((nC + 63) / 64), dim3(64), 0, s, h->bs_val, h->bs_diag, h->pcg_minv, nC, pc,
                      h->status, h->try_id);
-  hipLaunchKernelGGL(k_pcg_start, dim3(g), dim3(256), 0, s, h->bs_ea, h->pcg_minv, x, r, z, p, q, n, pc);
-  const unsigned gb = (unsigned)((6 * h->bs_nblk + 255) / 256);
+  hipLaunchKernelGGL(k_pcg_start, dim3(g), dim3(256), 0, s, h->bs_ea, h->pcg_minv, x, r0, z, p, q, n, pc);
   double hs[PC_N];
   h->pcg_iters = 0;
   h->pcg_relres = 1.0;
   const double tol2 = h->pcg_tol * h->pcg_tol;
   for (int it = 0; it < h->pcg_maxit;) {
     const int burst = it + 8 < h->pcg_maxit ? 8 : h->pcg_maxit - it;
+    int last = it;
     for (int k = 0; k < burst; k++, it++) {
-      hipLaunchKernelGGL(k_bsr_spmv, dim3(gb), dim3(256), 0, s, h->bs_val, h->bs_jk, h->bs_nblk, p, q);
-      hipLaunchKernelGGL(k_pcg_dot, dim3(g), dim3(256), 0, s, p, q, n, pc + PC_PQ);
-      hipLaunchKernelGGL(k_pcg_step1, dim3(g), dim3(256), 0, s, x, r, p, q, n, pc, h->status, h->try_id);
-      if (k == burst - 1)  // the scalars of this burst's last iteration, before they roll over
+      double *rc = (it & 1) ? r1 : r0, *rn = (it & 1) ? r0 : r1;
+      hipLaunchKernelGGL(k_pcg_spmv, dim3((nC + 3) / 4), dim3(256), 0, s, h->bs_val, h->bs_rowptr, h->bs_rowent, nC, p, q, pc, it);
+      hipLaunchKernelGGL(k_pcg_update, dim3(g), dim3(256), 0, s, x, rc, rn, p, q, h->pcg_minv, z, n, pc, it, h->status,
+                         h->try_id);
+      if (k == burst - 1) {  // the scalars of this burst's last iteration
         PSBA_HIP(h, hipMemcpyAsync(h->pcg_host, pc, sizeof(double) * PC_N, hipMemcpyDeviceToHost, s));
-      hipLaunchKernelGGL(k_pcg_precond, dim3(g), dim3(256), 0, s, r, h->pcg_minv, z, n, pc);
-      hipLaunchKernelGGL(k_pcg_step2, dim3(g), dim3(256), 0, s, z, p, n, pc);
-      hipLaunchKernelGGL(k_pcg_roll, dim3(1), dim3(1), 0, s, pc);
+        last = it;
+      }
+      hipLaunchKernelGGL(k_pcg_direction, dim3(g), dim3(256), 0, s, z, p, n, pc, it);
     }
     PSBA_HIP(h, hipGetLastError());
     PSBA_HIP(h, hipStreamSynchronize(s));
     for (int k = 0; k < PC_N; k++) hs[k] = h->pcg_host[k];
     h->pcg_iters = it;
     if (hs[PC_FAIL] != 0.0) break;
-    h->pcg_relres = hs[PC_BB] > 0.0 ? sqrt(hs[PC_RR] / hs[PC_BB]) : 0.0;
-    if (!(hs[PC_RR] > tol2 * hs[PC_BB])) break;
+    const double rr = hs[PC_RR + (last & 3)];
+    h->pcg_relres = hs[PC_BB] > 0.0 ? sqrt(rr / hs[PC_BB]) : 0.0;
+    if (!(rr > tol2 * hs[PC_BB])) break;
   }
   return PSBA_OK;
 }

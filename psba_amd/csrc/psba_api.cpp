@@ -153,6 +153,8 @@ static void free_problem_buffers(psba_ctx *h) {
   h->bs_ea = nullptr;
   dev_free(h->bs_jk);
   dev_free(h->bs_diag);
+  dev_free(h->bs_rowptr);
+  dev_free(h->bs_rowent);
   dev_free(h->pcg_vec);
   dev_free(h->pcg_minv);
   dev_free(h->pcg_scal);
@@ -435,10 +437,33 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     TRY(dev_alloc(h, &h->bs_diag, op.diag_slot.size()));
     PSBA_HIP(h, hipMemcpy(h->bs_jk, op.blocks.data(), sizeof(int2) * op.blocks.size(), hipMemcpyHostToDevice));
     PSBA_HIP(h, hipMemcpy(h->bs_diag, op.diag_slot.data(), sizeof(int) * op.diag_slot.size(), hipMemcpyHostToDevice));
-    TRY(dev_alloc(h, &h->pcg_vec, (size_t)4 * d.nA));
+    {  // the symmetric pattern by block row (kernels_pcg.hip, k_pcg_spmv)
+      std::vector<int> rp((size_t)nCams + 1, 0);
+      for (const int2 &b : op.blocks) {
+        rp[(size_t)b.x + 1]++;
+        if (b.x != b.y) rp[(size_t)b.y + 1]++;
+      }
+      for (int j = 0; j < nCams; j++) rp[(size_t)j + 1] += rp[(size_t)j];
+      std::vector<int2> ent((size_t)rp[(size_t)nCams]);
+      std::vector<int> at(rp.begin(), rp.end() - 1);
+      for (size_t sl = 0; sl < op.blocks.size(); sl++) {
+        const int2 b = op.blocks[sl];
+        if (b.x == b.y) {
+          ent[(size_t)at[(size_t)b.x]++] = make_int2((int)sl, b.x | (2 << 28));
+        } else {
+          ent[(size_t)at[(size_t)b.x]++] = make_int2((int)sl, b.y);
+          ent[(size_t)at[(size_t)b.y]++] = make_int2((int)sl, b.x | (1 << 28));
+        }
+      }
+      TRY(dev_alloc(h, &h->bs_rowptr, rp.size()));
+      TRY(dev_alloc(h, &h->bs_rowent, ent.size()));
+      PSBA_HIP(h, hipMemcpy(h->bs_rowptr, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice));
+      PSBA_HIP(h, hipMemcpy(h->bs_rowent, ent.data(), sizeof(int2) * ent.size(), hipMemcpyHostToDevice));
+    }
+    TRY(dev_alloc(h, &h->pcg_vec, (size_t)5 * d.nA));  // r, z, p, q, and r's second buffer
     TRY(dev_alloc(h, &h->pcg_minv, (size_t)36 * d.nC));
-    TRY(dev_alloc(h, &h->pcg_scal, (size_t)8));
-    if (!h->pcg_host && hipHostMalloc((void **)&h->pcg_host, sizeof(double) * 8) != hipSuccess)
+    TRY(dev_alloc(h, &h->pcg_scal, (size_t)(16 + 4 * 64)));  // scalars + the partial sums of p.Sp (kernels_pcg.hip)
+    if (!h->pcg_host && hipHostMalloc((void **)&h->pcg_host, sizeof(double) * 16) != hipSuccess)
       return fail(h, PSBA_E_NOMEM, "no pinned memory for the PCG scalars");
     if (getenv("PSBA_SCHUR_PLAN_INFO"))
       fprintf(stderr, "[psba] block-sparse S: %lld of %lld blocks of the lower block triangle (%.1f %%), %lld products\n",

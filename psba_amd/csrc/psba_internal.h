@@ -231,6 +231,11 @@ struct psba_ctx {
   double *bs_ea = nullptr;      // = bs_val + 36 bs_nblk
   int2 *bs_jk = nullptr;        // [bs_nblk] (j, k)
   int *bs_diag = nullptr;       // [nC] index of block (j, j)
+  // the full symmetric pattern by block row, for the product S p without atomics: row j's entries
+  // [bs_rowptr[j], bs_rowptr[j + 1]) = (slot of the stored block, other camera | how to read it << 28:
+  // 0 as stored (j is the block's row), 1 transposed (j is its column), 2 the diagonal block)
+  int *bs_rowptr = nullptr;
+  int2 *bs_rowent = nullptr;
   double *pcg_vec = nullptr;    // r | z | p | q, nA each
   double *pcg_minv = nullptr;   // [nC][36] inverses of the diagonal blocks
   double *pcg_scal = nullptr, *pcg_host = nullptr;  // device scalars and their pinned mirror
