@@ -19,12 +19,21 @@ Workload (config.workload):
   cfg5            BASELINE configs[4]: 2000 cameras on a circle, 10 views per point, dense
                   12000 x 12000 S on the MFMA panel chain; --cfg5-points scales the point count
                   (default 200000 = 2 M observations; 2000000 is the full configuration)
-Multi-GPU: 3-D points are sharded over ranks and [S | ea] is summed with one RCCL all-reduce per
-damping try.  --scaling weak (default): every rank owns its own shard of the workload's size over
-the same cameras.  --scaling strong: ONE problem of the workload's size is split over the ranks
-with psba_partition_points -- BASELINE configs[3] is
+Multi-GPU: 3-D points are sharded over ranks and [tril(S) | ea] is summed with one RCCL all-reduce per
+damping try.  --scaling strong (default): ONE problem of the workload's size is split over the ranks
+with psba_partition_points -- the north star's 1/2/4/8-GPU figures and BASELINE configs[3]
+("Venice-52-64053, points sharded across 4 MI355X") are this:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
-      bench.py --gpus 4 --scaling strong
+      bench.py --gpus 4            (or simply: python bench.py --gpus 4, see below)
+--scaling weak: every rank owns its own shard of the workload's size over the same cameras.  With N > 1
+the strong line also carries the weak figure and a sharded cfg5 figure (2000 cameras, 200 k points split
+over the ranks, the dense factorization's wide update sharded by block column) as extra keys, with the
+bytes each collective moves per damping try.
+Launch: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) every
+process is one rank.  Started plainly as `python bench.py --gpus N` with N > 1 and no WORLD_SIZE, this
+process only SPAWNS the N ranks -- as child processes, before it has imported the library or touched a
+GPU (never a re-exec of a process that has initialised the GPU) --, relays rank 0's JSON line and exits
+non-zero if any rank failed.
 """
 import argparse
 import json
@@ -37,8 +46,77 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-import psba_amd  # noqa: E402  (loads the HIP library before torch brings its own runtime)
-from psba_amd import capi, synth  # noqa: E402
+# psba_amd (which loads the HIP library) is imported by load_library(), called from main() AFTER the decision
+# to spawn ranks: the spawning parent must not initialise a GPU runtime.
+psba_amd = capi = synth = None
+
+
+def load_library():
+    global psba_amd, capi, synth
+    import psba_amd as _p  # loads the HIP library before torch brings its own runtime
+    from psba_amd import capi as _c, synth as _s
+    psba_amd, capi, synth = _p, _c, _s
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N children of this very command line, one per
+    GPU, with the rendezvous variables torch.distributed.run would set; rank 0's stdout is captured and
+    its JSON line printed once; every other output goes to stderr.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:  # rank 0 is gone and this one hangs in a collective
+            p.kill()
+            codes.append(p.wait())
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines[-1:]:
+            print(ln, file=sys.stderr)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or not json_lines:
+        print(f"[bench] ranks failed (rank, exit code): {bad}; JSON lines from rank 0: {len(json_lines)}", file=sys.stderr)
+        return next((c for _, c in bad if c), 1) or 1
+    print(json_lines[-1], flush=True)
+    return 0
+
+
+def stub_rank(args, rank, world):
+    """PSBA_BENCH_STUB=1 (tests/test_host.py): the launch plumbing without the GPU work -- rendezvous over
+    gloo, barrier, max over ranks, ONE JSON line from rank 0, labelled as a stub (value null)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+    dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if os.environ.get("PSBA_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(7)
+    if rank == 0:
+        print("a stray line on rank 0's stdout (RCCL banners look like this)")
+        print(json.dumps({"stub": True, "metric": "stub", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": args.scaling, "ranks_seen": seen,
+                          "max_over_ranks": float(t[0])}), flush=True)
+    else:
+        print(f"rank {rank} says hello on its stdout")  # must not reach the parent's stdout
+    dist.destroy_process_group()
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor figure quoted in SURVEY.md 8(d): fp64 vector (= matrix) peak; = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
@@ -151,75 +229,94 @@ def cfg5_extra(device):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="venice-shaped")
-    ap.add_argument("--segment", type=int, default=10, help="LM iterations per restart segment")
-    ap.add_argument("--cpu-iters", type=int, default=30, help="LM iterations of the CPU baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--cfg5-points", type=int, default=200000, help="points of the cfg5 workload (2000000 = full)")
-    ap.add_argument("--spread-segments", type=int, default=10,
-                    help="extra segments timed one by one after the K steps, for the median / spread fields")
-    args = ap.parse_args()
+class Ranks:
+    """The launcher-side plumbing of one rank: rendezvous, barrier, max / sum over ranks (gloo; the
+    data-path collectives are RCCL inside the library, on the library's stream)."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
 
-    dist = None
-    if world > 1:
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.dist is None:
+            return x
         import torch
-        import torch.distributed as dist
-        # torch.distributed is the launcher-side plumbing (rendezvous, barrier, max over ranks);
-        # the data-path collective is RCCL inside the library, on the library's stream.
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
 
-    file_workload = args.workload in ("54cams", "trafalgar21")
-    strong = args.scaling == "strong" or file_workload
-    prob, data_kind = load_workload(args.workload, rank, world, strong, args.cfg5_points)
-    h = psba_amd.Psba(local_rank)  # one process per GPU (RCCL refuses two ranks on one device)
-    if world > 1:
-        uid = [psba_amd.Psba.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        # RCCL prints a version banner on stdout at communicator creation; stdout carries exactly
-        # one JSON line, so the banner goes to stderr
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            h.comm_init(world, rank, uid[0])
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
-    h.upload_problem(prob)
+    def sum_ints(self, xs):
+        if self.dist is None:
+            return [int(x) for x in xs]
+        import torch
+        t = torch.tensor(list(xs), dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(x) for x in t]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def handle(self, prob):
+        """One handle on this rank's GPU with the problem uploaded, inside a fresh communicator if N > 1."""
+        h = psba_amd.Psba(self.local_rank)  # one process per GPU (RCCL refuses two ranks on one device)
+        if self.world > 1:
+            uid = [psba_amd.Psba.comm_unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(uid, src=0)
+            # RCCL prints a version banner on stdout at communicator creation; stdout carries exactly
+            # one JSON line, so the banner goes to stderr
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                h.comm_init(self.world, self.rank, uid[0])
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        h.upload_problem(prob)
+        return h
 
-    def run_steps(n):
-        """n LM iterations in segments that restart from the initial parameters; returns
-        (iterations done, damping tries, last result)."""
-        done = tries = 0
-        res = None
-        while done < n:
-            ts = time.perf_counter()
-            h.reset_params()  # the uploaded (initial) parameters again, device side
-            res, _ = h.levmar(max_iter=min(args.segment, n - done), tr_handoff=False, log_cap=0)
-            if os.environ.get("PSBA_BENCH_DEBUG"):
-                print(f"[bench] segment of {res.iters}: {1e6 * (time.perf_counter() - ts):.1f} us", file=sys.stderr)
-            if res.iters == 0:
-                raise SystemExit("LM made no iteration: cannot time steps")
-            done += res.iters
-            tries += res.tries
-        return done, tries, res
 
+def collective_bytes(n_cams, world, chol_sharded):
+    """Bytes one rank hands to RCCL per damping try: the all-reduce of [tril(S) | e_a] in
+    canonical block order (e_a rides in the diagonal blocks), the all-reduce of the try's scalars (16 partial
+    sets of 4 sums + 2 status flags), and -- when the dense factorization's wide update is sharded -- the
+    broadcasts of the factor's 64-column blocks (the lower triangle once per factorization)."""
+    if world == 1:
+        return {"allreduce_S_ea": 0, "allreduce_scalars": 0, "broadcast_factor_columns": 0}
+    nA = 6 * n_cams
+    n32 = (nA + 31) // 32 * 32
+    return {"allreduce_S_ea": n_cams * (n_cams + 1) // 2 * 36 * 8, "allreduce_scalars": 66 * 8,
+            "broadcast_factor_columns": (n32 * (n32 + 1) // 2 + n32) * 8 if chol_sharded else 0}
+
+
+def run_steps(h, n, segment):
+    """n LM iterations in segments that restart from the initial parameters; returns
+    (iterations done, damping tries, last result)."""
+    done = tries = 0
+    res = None
+    while done < n:
+        ts = time.perf_counter()
+        h.reset_params()  # the uploaded (initial) parameters again, device side
+        res, _ = h.levmar(max_iter=min(segment, n - done), tr_handoff=False, log_cap=0)
+        if os.environ.get("PSBA_BENCH_DEBUG"):
+            print(f"[bench] segment of {res.iters}: {1e6 * (time.perf_counter() - ts):.1f} us", file=sys.stderr)
+        if res.iters == 0:
+            raise SystemExit("LM made no iteration: cannot time steps")
+        done += res.iters
+        tries += res.tries
+    return done, tries, res
+
+
+def timed_pass(rk, h, prob, steps, warmup, segment, spread_segments=0, settle=True):
+    """Settle, W untimed warm-up iterations, then EXACTLY `steps` LM iterations between barriers, MAX over
+    ranks.  Returns a dict (elapsed seconds, steps done, tries, totals over ranks, the graded pair's time)."""
     # HIP events on the graded kernel only during the timed region (every timed launch costs two
     # event records on the stream); the other kernel classes are timed in an extra pass afterwards.
     # Enabled before anything runs, so that the event pool is created AND used before the timing
@@ -230,43 +327,26 @@ def main():
     # once or twice early on (PSBA_BENCH_DEBUG=1 prints the segment times).  Untimed segments are
     # run until three in a row agree to 2 % (at least 12, at most 60: 25-120 ms), which puts that
     # behind us whatever W and K are.
-    if not os.environ.get("PSBA_BENCH_NO_SETTLE"):
+    if settle and not os.environ.get("PSBA_BENCH_NO_SETTLE"):
         times = []
         while len(times) < 60:
             ts = time.perf_counter()
-            run_steps(args.segment)
-            times.append(time.perf_counter() - ts)
-            if dist is not None:  # every rank must take the same number of segments
-                import torch
-                t = torch.tensor([times[-1]], dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                times[-1] = float(t[0])
+            run_steps(h, segment, segment)
+            times.append(rk.max(time.perf_counter() - ts))  # every rank must take the same number of segments
             if len(times) >= 12 and max(times[-3:]) <= 1.02 * min(times[-3:]):
                 break
             if len(times) >= 3 and times[-1] > 0.25:  # long steps (cfg5): three segments are plenty
                 break
-    # warmup: W untimed LM iterations
-    if args.warmup > 0:
-        run_steps(args.warmup)
+    if warmup > 0:
+        run_steps(h, warmup, segment)
     h.profile_reset()
-    barrier()
+    rk.barrier()
     t0 = time.perf_counter()
-    steps_done, tries_done, res = run_steps(args.steps)  # every levmar call returns with its stream drained
+    steps_done, tries_done, res = run_steps(h, steps, segment)  # every levmar call returns with its stream drained
     t1 = time.perf_counter()
-    barrier()
-    elapsed = t1 - t0
-    n_obs_total = prob["nO"]
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        n = torch.tensor([prob["nO"], prob["nP"]], dtype=torch.int64)
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        n_obs_total, n_pts_total = int(n[0]), int(n[1])
-    else:
-        n_pts_total = prob["nP"]
-    kern = {}
+    rk.barrier()
+    elapsed = rk.max(t1 - t0)
+    n_obs_total, n_pts_total = rk.sum_ints([prob["nO"], prob["nP"]])
     # PSBA_K_SCHUR alone in the mask = ONE span over k_schur_lds + k_schur_reduce: S does not exist
     # before the reduce ends, so the pair is what the roofline is quoted on
     ms, n = h.profile_get(capi.K_SCHUR)
@@ -274,25 +354,87 @@ def main():
     # spread: further segments, each timed by itself (max over ranks), outside the K timed steps
     seg_ms = []
     h.profile_enable(0)
-    for _ in range(max(args.spread_segments, 0)):
-        barrier()
+    for _ in range(max(spread_segments, 0)):
+        rk.barrier()
         ts = time.perf_counter()
-        d_, _, _ = run_steps(args.segment)
-        dt = time.perf_counter() - ts
-        if dist is not None:
-            import torch
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
-        seg_ms.append(1e3 * dt / max(d_, 1))
-    h.profile_enable(True)  # untimed extra pass: per-kernel times of every class, each by itself
+        d_, _, _ = run_steps(h, segment, segment)
+        seg_ms.append(1e3 * rk.max(time.perf_counter() - ts) / max(d_, 1))
+    return {"elapsed": elapsed, "steps_done": steps_done, "tries": tries_done, "res": res, "n_obs": n_obs_total,
+            "n_pts": n_pts_total, "pair_us": pair_us, "seg_ms": seg_ms}
+
+
+def per_kernel_pass(h, steps, segment):
+    """Untimed extra pass: HIP-event time of every kernel class, each by itself."""
+    kern = {}
+    h.profile_enable(True)
     h.profile_reset()
-    run_steps(min(args.steps, args.segment))
+    run_steps(h, min(steps, segment), segment)
     for k, name in enumerate(capi.KERNEL_NAMES):
         ms, n = h.profile_get(k)
         if n:
             kern[name] = {"avg_us": 1e3 * ms / n, "launches": n}
     h.profile_enable(False)
+    return kern
+
+
+def extra_multi_gpu(rk, workload, strong, steps, warmup, segment, cfg5_points):
+    """One more measured configuration of an N > 1 run (an extra key of the JSON line)."""
+    prob, _ = load_workload(workload, rk.rank, rk.world, strong, cfg5_points)
+    h = rk.handle(prob)
+    chol_sharded = bool(h.chol_dist_shape()[2]) and not os.environ.get("PSBA_CHOL_REPLICATED")
+    r = timed_pass(rk, h, prob, steps, warmup, segment, settle=(workload != "cfg5"))
+    kern = per_kernel_pass(h, steps, segment)
+    h.close()
+    return {"workload": workload + (f" split over {rk.world} ranks" if strong else f" x{rk.world} shards"),
+            "scaling": "strong" if strong else "weak", "n_cams": int(prob["nC"]), "n_pts": r["n_pts"], "n_obs": r["n_obs"],
+            "steps": r["steps_done"], "damping_tries": r["tries"],
+            "ms_per_lm_iter": 1e3 * r["elapsed"] / max(r["steps_done"], 1),
+            "M_obs_per_s": r["n_obs"] * r["steps_done"] / r["elapsed"] / 1e6, "final_cost": r["res"].final_err,
+            "kernels_us_rank0": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "dense_factorization": "wide update sharded by 64-column block" if chol_sharded else "replicated",
+            "bytes_per_try_per_rank": collective_bytes(int(prob["nC"]), rk.world, chol_sharded)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="venice-shaped")
+    ap.add_argument("--segment", type=int, default=10, help="LM iterations per restart segment")
+    ap.add_argument("--cpu-iters", type=int, default=30, help="LM iterations of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong = ONE problem split over the ranks (north star, BASELINE configs[3]); "
+                         "weak = one shard of the workload's size per rank")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the weak-scaling and sharded-cfg5 extra keys")
+    ap.add_argument("--cfg5-points", type=int, default=200000, help="points of the cfg5 workload (2000000 = full)")
+    ap.add_argument("--spread-segments", type=int, default=10,
+                    help="extra segments timed one by one after the K steps, for the median / spread fields")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher.  Nothing above has touched a GPU runtime.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("PSBA_BENCH_STUB"):
+        return stub_rank(args, int(os.environ.get("RANK", "0")), world)
+
+    load_library()
+    rk = Ranks()
+    rank, local_rank = rk.rank, rk.local_rank
+
+    file_workload = args.workload in ("54cams", "trafalgar21")
+    strong = args.scaling == "strong" or file_workload
+    prob, data_kind = load_workload(args.workload, rank, world, strong, args.cfg5_points)
+    h = rk.handle(prob)
+    chol_sharded = world > 1 and bool(h.chol_dist_shape()[2]) and not os.environ.get("PSBA_CHOL_REPLICATED")
+    r = timed_pass(rk, h, prob, args.steps, args.warmup, args.segment, args.spread_segments)
+    elapsed, steps_done, tries_done, res = r["elapsed"], r["steps_done"], r["tries"], r["res"]
+    n_obs_total, n_pts_total, pair_us, seg_ms = r["n_obs"], r["n_pts"], r["pair_us"], r["seg_ms"]
+    kern = per_kernel_pass(h, args.steps, args.segment)
 
     out = None
     if rank == 0:
@@ -300,25 +442,30 @@ def main():
         sch_us = pair_us
         achieved = sch_bytes / (sch_us * 1e-6) / 1e9 if sch_us == sch_us and sch_us > 0 else float("nan")
         seg_sorted = sorted(seg_ms)
+        config = {"workload": args.workload + ("" if world == 1 else
+                                               (f" split over {world} ranks" if strong else f" x{world} shards")),
+                  "n_cams": int(prob["nC"]), "n_pts": n_pts_total, "n_obs": n_obs_total,
+                  "lm": "levmar, TR hand-off disabled", "parallelism": f"points sharded x{world}"}
+        if data_kind == "synthetic":
+            config["tracks"] = ("uniform-random cameras per point (SURVEY 8d stand-in; worst case for block locality: "
+                                "two neighbouring points share a block of S with probability ~1 %)")
         out = {
             "metric": "M-observations/sec through Jacobian+Schur build+solve (ms/LM-iter in ms_per_step)",
             "value": n_obs_total * steps_done / elapsed / 1e6,
             "unit": "M-obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
-            "higher_is_better": True, "scaling": "strong" if (strong and world > 1) else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": data_kind,
-            "config": {"workload": args.workload + ("" if world == 1 else
-                                                    (f" split over {world} ranks" if strong else f" x{world} shards")),
-                       "n_cams": int(prob["nC"]), "n_pts": n_pts_total, "n_obs": n_obs_total,
-                       "lm": "levmar, TR hand-off disabled", "parallelism": f"points sharded x{world}"},
+            "config": config,
             "steps_completed": steps_done, "damping_tries": tries_done, "lm_flag": res.flag, "segment": args.segment,
             "init_cost": res.init_err, "final_cost": res.final_err,
             # the K timed steps are one sample; these are further segments of the same length timed one
             # by one right after it (ms per LM iteration)
             "ms_per_step_segments": ({"n": len(seg_ms), "median": seg_sorted[len(seg_sorted) // 2],
                                       "min": seg_sorted[0], "max": seg_sorted[-1]} if seg_ms else None),
-            "schur_path": {0: "lds-partitions", 1: "owner (products sorted by camera pair)", 2: "global-atomics", 3: "ring (owner lanes, LDS-DMA operand ring)"}[h.schur_path()],
+            "schur_path": {0: "lds-partitions", 1: "owner (products sorted by camera pair)", 2: "global-atomics",
+                           3: "ring (experiment)", 4: "block-sparse (owner)"}.get(h.schur_path(), str(h.schur_path())),
             "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
             "roofline": {"kernel": "schur assemble (W/Y/S/ea): k_schur_lds + k_schur_reduce, one HIP-event span over both",
                          "bound": "hbm", "achieved": achieved,
@@ -326,6 +473,10 @@ def main():
                          "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
                          "traffic": None},
         }
+        if world > 1:
+            out["multi_gpu"] = {"hardware_note": "first N > 1 measurements come from the driver's node: the builder has one GPU",
+                                "dense_factorization": "wide update sharded by 64-column block" if chol_sharded else "replicated",
+                                "bytes_per_try_per_rank": collective_bytes(int(prob["nC"]), world, chol_sharded)}
         # SURVEY 8(d) also asks for the kernel's FP64 rate: nP*50 (V^-1) + nO*(108 Y + 36 e_a) +
         # P_sym*216 flops per launch, P_sym = sum_i k_i (k_i + 1) / 2 products
         ii = np.asarray(prob["iidx"])
@@ -394,6 +545,20 @@ def main():
                     "final_cost": pres.final_err,
                 }
     h.close()
+    # N > 1, default workload: the other two multi-GPU configurations as extra keys (every rank takes part)
+    if world > 1 and args.workload == "venice-shaped" and not args.no_extras:
+        extras = {}
+        for key, (wl, st, steps, warm) in {("weak_scaling" if strong else "strong_scaling"):
+                                           ("venice-shaped", not strong, args.steps, args.warmup),
+                                           "cfg5_sharded": ("cfg5", True, 4, 1)}.items():
+            try:
+                extras[key] = extra_multi_gpu(rk, wl, st, steps, warm, args.segment if wl != "cfg5" else 2, args.cfg5_points)
+            except BaseException as e:  # a rank that drops out here would hang the others in a collective:
+                print(f"[bench] rank {rank}: extra {key} failed: {e!r}", file=sys.stderr)  # say so and stop the extras
+                extras[key] = {"error": repr(e)}
+                break
+        if rank == 0:
+            out.update(extras)
     if rank == 0:
         # the full-size cfg5 in the driver's view (an extra key, never the headline value)
         if world == 1 and args.workload == "venice-shaped" and not os.environ.get("PSBA_BENCH_NO_CFG5"):
@@ -402,8 +567,8 @@ def main():
             except Exception as e:  # the headline line must not depend on the extra
                 out["cfg5_full_size"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if rk.dist is not None:
+        rk.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -38,6 +38,8 @@ typedef struct psba_ctx *psba_handle;
                               PSBA/cl_spdinv.cpp:85-102, CL_files/SPD_inv.cl:35-38,66) */
 #define PSBA_SINGULAR_V 2  /* some |det V_i| < 1e-16 (compute_Vinv ret==1.0,
                               CL_files/compute_Vinv.cl:31-32) */
+#define PSBA_PCG_MAXIT 4   /* psba_schur_solve under PSBA_SOLVER_PCG: max_iter iterations without reaching
+                              tol; dpa holds the last iterate (an inexact step), psba_pcg_info the residual */
 #define PSBA_E_INVALID (-1)
 #define PSBA_E_HIP (-2)
 #define PSBA_E_RCCL (-3)
@@ -196,6 +198,7 @@ typedef struct {
   double init_err, final_err, mu0, mu_final;
   int n_log;
   double seconds;   /* wall time inside the loop */
+  int pcg_unconverged; /* PSBA_SOLVER_PCG: solves of this call that returned PSBA_PCG_MAXIT */
 } psba_lm_result;
 
 void psba_lm_default_options(psba_lm_options *o);
@@ -334,7 +337,10 @@ int psba_algorithmic_bytes(psba_handle h, int kernel, double *bytes);
  * common point exist (the lower block triangle as a list; no dense buffer is allocated), and
  * psba_schur_solve runs conjugate gradients with a block-Jacobi preconditioner until
  * ||S x - e_a|| <= tol ||e_a|| or max_iter iterations; a diagonal block that is not positive definite or
- * a direction of non-positive curvature reports PSBA_NOT_SPD, so psba_levmar works unchanged.  The
+ * a direction of non-positive curvature reports PSBA_NOT_SPD, so psba_levmar works unchanged; a solve
+ * that uses up max_iter returns PSBA_PCG_MAXIT (> 0: the step is usable, the LM gain ratio judges it, and
+ * psba_levmar counts such solves in psba_lm_result.pcg_unconverged); e_a == 0 or an exactly solved system
+ * is a converged solve with x as it stands, not a break-down.  The
  * sba_func.h mirror verbs and the trust-region operators need the dense S and refuse this mode.
  * Sharded points: every rank must hold the same block list, the union of the blocks its ranks' points
  * produce.  With a communicator psba_upload_problem forms it by itself (one max all-reduce of a byte per

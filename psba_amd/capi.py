@@ -38,7 +38,7 @@ class LmOptions(C.Structure):
 class LmResult(C.Structure):
     _fields_ = [("flag", C.c_int), ("iters", C.c_int), ("tries", C.c_int), ("init_err", C.c_double),
                 ("final_err", C.c_double), ("mu0", C.c_double), ("mu_final", C.c_double),
-                ("n_log", C.c_int), ("seconds", C.c_double)]
+                ("n_log", C.c_int), ("seconds", C.c_double), ("pcg_unconverged", C.c_int)]
 
 
 class TrOptions(C.Structure):
@@ -422,7 +422,8 @@ class Psba:
         self._ck(lib.psba_schur_reduce(self._h))
 
     def schur_solve(self):
-        self._ck(lib.psba_schur_solve(self._h))
+        """PSBA_OK, or PSBA_PCG_MAXIT (4) when the iterative solve used up max_iter (the iterate is kept)."""
+        return self._ck(lib.psba_schur_solve(self._h))
 
     def backsub(self, mu):
         s = TryScalars()

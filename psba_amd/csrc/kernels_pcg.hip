@@ -24,7 +24,21 @@ namespace psba {
 // ever zeroed while a kernel in flight reads or adds to it, and nothing has to be rolled over
 // (p.Sp is added up by thousands of workgroups: it goes into 64 partial sums per slot, PC_PQ + 64 slot + k,
 // because same-address atomics serialise at ~13 ns each -- 1800 of them were 24 us per iteration)
-enum { PC_BB = 0, PC_FAIL = 1, PC_RR = 4, PC_RZ = 8, PC_N = 16, PC_PQ = 16, PC_NPQ = 64, PC_ALL = 16 + 4 * 64 };
+// PC_DONE / PC_RRFIN: iterations done and r.r when the residual test first held (written once, by one
+// thread; the decision itself is taken by every thread from sums that are final before the kernel
+// starts, so all workgroups of a launch agree without a hand-shake)
+enum { PC_BB = 0, PC_FAIL = 1, PC_DONE = 2, PC_RRFIN = 3, PC_RR = 4, PC_RZ = 8, PC_N = 16, PC_PQ = 16, PC_NPQ = 64,
+       PC_ALL = 16 + 4 * 64 };
+
+// has the solve converged before iteration `it`?  r.z of this iteration and r.r of the previous one
+// are complete when iteration `it`'s kernels run.  r.z == 0 means r == 0 (M is positive definite):
+// e_a == 0 or an exact solution -- a solved system, not a break-down.  Once true it stays true: the
+// kernels then leave x, r, p and the sums alone, so the later slots stay zero.
+__device__ __forceinline__ bool pcg_converged_before(const double *pc, int it, double tol2) {
+  const double rz = pc[PC_RZ + (it & 3)];
+  if (rz == 0.0) return true;
+  return it > 0 && pc[PC_RR + ((it - 1) & 3)] <= tol2 * pc[PC_BB];
+}
 
 // diagonal blocks += U_j + mu I (rank 0 adds mu), e_a += g_a, the try's accumulators of K3 zeroed
 __global__ __launch_bounds__(256) void k_bsr_finalize(double *val, const int *diag_slot, double *ea, const double *U,
@@ -192,8 +206,15 @@ __global__ __launch_bounds__(256) void k_pcg_start(const double *b, const double
 // update and the preconditioner are one pass; r.r and the next r.z with it
 __global__ __launch_bounds__(256) void k_pcg_update(double *x, const double *r, double *rn, const double *p, const double *q,
                                                     const double *minv, double *z, int n, double *pc, int it, int *status,
-                                                    int try_id) {
+                                                    int try_id, double tol2) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (pcg_converged_before(pc, it, tol2)) {  // the rest of a burst after convergence: nothing to do
+    if (t == 0 && pc[PC_DONE] == 0.0) {
+      pc[PC_RRFIN] = it > 0 ? pc[PC_RR + ((it - 1) & 3)] : 0.0;
+      pc[PC_DONE] = (double)(it + 1);  // it iterations were carried out (+1: zero means "not yet")
+    }
+    return;
+  }
   __shared__ double sPq;
   if (threadIdx.x < 64) {  // the 64 partial sums of p.Sp
     double v = pc[PC_PQ + PC_NPQ * (it & 3) + threadIdx.x];
@@ -241,7 +262,9 @@ __global__ __launch_bounds__(256) void k_pcg_direction(const double *z, double *
     pc[PC_RZ + ((it + 3) & 3)] = 0.0;
   }
   if (t >= n) return;
-  const double beta = pc[PC_RZ + ((it + 1) & 3)] / pc[PC_RZ + (it & 3)];
+  const double rz = pc[PC_RZ + (it & 3)];
+  if (rz == 0.0) return;  // converged before this iteration (0 / 0 otherwise): p stays as it is
+  const double beta = pc[PC_RZ + ((it + 1) & 3)] / rz;
   p[t] = z[t] + beta * p[t];
 }
 
@@ -269,6 +292,7 @@ int launch_pcg_solve(psba_ctx *h) {
   h->pcg_iters = 0;
   h->pcg_relres = 1.0;
   const double tol2 = h->pcg_tol * h->pcg_tol;
+  bool converged = false, failed = false;
   for (int it = 0; it < h->pcg_maxit;) {
     const int burst = it + 8 < h->pcg_maxit ? 8 : h->pcg_maxit - it;
     int last = it;
@@ -276,7 +300,7 @@ int launch_pcg_solve(psba_ctx *h) {
       double *rc = (it & 1) ? r1 : r0, *rn = (it & 1) ? r0 : r1;
       hipLaunchKernelGGL(k_pcg_spmv, dim3((nC + 3) / 4), dim3(256), 0, s, h->bs_val, h->bs_rowptr, h->bs_rowent, nC, p, q, pc, it);
       hipLaunchKernelGGL(k_pcg_update, dim3(g), dim3(256), 0, s, x, rc, rn, p, q, h->pcg_minv, z, n, pc, it, h->status,
-                         h->try_id);
+                         h->try_id, tol2);
       if (k == burst - 1) {  // the scalars of this burst's last iteration
         PSBA_HIP(h, hipMemcpyAsync(h->pcg_host, pc, sizeof(double) * PC_N, hipMemcpyDeviceToHost, s));
         last = it;
@@ -287,11 +311,24 @@ int launch_pcg_solve(psba_ctx *h) {
     PSBA_HIP(h, hipStreamSynchronize(s));
     for (int k = 0; k < PC_N; k++) hs[k] = h->pcg_host[k];
     h->pcg_iters = it;
-    if (hs[PC_FAIL] != 0.0) break;
-    const double rr = hs[PC_RR + (last & 3)];
+    if (hs[PC_FAIL] != 0.0) {
+      failed = true;
+      break;
+    }
+    double rr = hs[PC_RR + (last & 3)];
+    if (hs[PC_DONE] != 0.0) {  // the test held inside the burst: the device stopped iterating there
+      h->pcg_iters = (int)hs[PC_DONE] - 1;
+      rr = hs[PC_RRFIN];
+      converged = true;
+    } else if (rr <= tol2 * hs[PC_BB]) {  // ... or in its last iteration
+      converged = true;
+    }
     h->pcg_relres = hs[PC_BB] > 0.0 ? sqrt(rr / hs[PC_BB]) : 0.0;
-    if (!(rr > tol2 * hs[PC_BB])) break;
+    if (converged || !(rr == rr)) break;
   }
+  // max_iter iterations without reaching tol: the step is used as it is (an inexact Newton step; the gain
+  // ratio judges it), but the caller is told -- psba_schur_solve returns PSBA_PCG_MAXIT
+  h->pcg_exhausted = !converged && !failed;
   return PSBA_OK;
 }
 

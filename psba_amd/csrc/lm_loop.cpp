@@ -61,6 +61,15 @@ int psba_levmar(psba_handle h, const psba_lm_options *opts, psba_lm_result *res,
       LM_TRY(psba_schur_assemble(h, mu));  // :126-131
       LM_TRY(psba_schur_reduce(h));
       LM_TRY(psba_schur_solve(h));         // :134-140
+      if (rc == PSBA_PCG_MAXIT) {          // iterative solve only: an inexact step; rho judges it
+        res->pcg_unconverged++;
+        if (opts->verbose) {
+          int it = 0;
+          double rr = 0;
+          psba_pcg_info(h, &it, &rr, nullptr, nullptr);
+          printf("itno=%d\t\tpcg: %d iterations without reaching the tolerance, relres=%.3e\n", itno, it, rr);
+        }
+      }
       // :151-157,185-193 -- and, while the host looks at the scalars, the next iteration's
       // linearization at the proposed parameters (dropped if the step is rejected)
       LM_TRY(psba_backsub_async(h, mu));

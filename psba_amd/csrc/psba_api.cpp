@@ -769,7 +769,7 @@ int psba_schur_solve(psba_handle h) {
     TRY(launch_pcg_solve(h));
     h->assembled = false;
     h->solved = true;
-    return PSBA_OK;
+    return h->pcg_exhausted ? PSBA_PCG_MAXIT : PSBA_OK;
   }
   TRY(launch_chol_solve(h));
   if (h->chol_tim) {

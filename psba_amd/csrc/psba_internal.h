@@ -226,6 +226,7 @@ struct psba_ctx {
   double pcg_tol = 1e-10;
   int pcg_maxit = 500, pcg_iters = 0;
   double pcg_relres = 0.0;
+  bool pcg_exhausted = false;  // the last solve used up max_iter without reaching tol
   long long bs_nblk = 0;
   double *bs_val = nullptr;     // [bs_nblk][36] | e_a [nA] right behind (one all-reduce)
   double *bs_ea = nullptr;      // = bs_val + 36 bs_nblk

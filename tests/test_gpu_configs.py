@@ -369,17 +369,37 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     """only the blocks of S whose cameras see a common point are stored (the reference
     stores and inverts the dense S: CL_files/compute_S.cl:6-78, PSBA/cl_spdinv.cpp:18-40), and the
     reduced system is solved by block-Jacobi preconditioned conjugate gradients.  1000 cameras in a
-    sequence (a point's cameras within a window of 40): the stored blocks against the dense S of the
-    default route block by block, absent blocks exactly zero there, dpa against the dense
-    factorization's at 1e-8, and the LM run through the iterative solve against the dense one."""
+    sequence (a point's cameras within a window of 40).  First check, against the ORACLE (VERDICT r3:
+    the dense HIP route shares K1 and the owner route's product lists with the sparse one, so it
+    cannot be the only judge): stored blocks against Oracle.schur's S block by block, absent blocks
+    exactly zero there, e_a against the oracle's; at 60 cameras also dpa against Oracle.solve and
+    the six-iteration LM cost against Oracle.levmar (the oracle's plain-loop Cholesky takes minutes
+    at nA = 6000, so the 1000-camera case holds S / e_a to the oracle and the solve to LAPACK on
+    the oracle's S).  Second check: the same quantities against this library's dense route."""
     import psba_amd
     from psba_amd import capi
     import psba_amd.synth as synth
+    from oracle_lib import Oracle
     prob = synth.make_problem(n_cams=n_cams, n_pts=6000, mean_track=5.0, seed=77 + n_cams, window=window)
+    orc = Oracle(prob)
+    olin = orc.linearize()
+    omu = 1e-3 * olin["maxdiag"]
+    osch = orc.schur(olin, omu)
+    oS, oea = osch["S"], osch["eab"][: 6 * n_cams]
+    if n_cams <= 100:
+        ost, odp, _ = orc.solve(olin, osch)
+        assert ost == 0.0
+        odpa = odp[: 6 * n_cams]
+        owant, _ = Oracle(prob).levmar(max_iter=6, tr_handoff=False)
+    else:
+        odpa = np.linalg.solve(oS, oea)
+        owant = None
     ref = psba_amd.Psba(0)
     ref.upload_problem(prob)
     ref.linearize(1.0, 1.0)
     mu = 1e-3 * ref.max_diag()
+    assert abs(mu - omu) <= 1e-12 * omu
+    mu = omu
     ref.schur_assemble(mu)
     nA = 6 * n_cams
     n32 = (nA + 31) // 32 * 32
@@ -404,16 +424,19 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     assert nb == len(jk) and nd == n_cams * (n_cams + 1) // 2
     if window is not None:
         assert nb < 0.2 * nd  # the band and its wrap-around corner
-    scale = np.abs(S).max()
+    scale = np.abs(oS).max()
     present = np.zeros((n_cams, n_cams), dtype=bool)
     for (j, k), B in zip(jk, val):
         assert k <= j
         present[j, k] = True
-        want_blk = S[6 * j: 6 * j + 6, 6 * k: 6 * k + 6]
         got = B if j != k else np.tril(B) + np.tril(B, -1).T
-        assert np.abs(got - want_blk).max() <= 1e-11 * scale, (j, k)
-    blocks = np.abs(S.reshape(n_cams, 6, n_cams, 6)).max(axis=(1, 3))
-    assert np.all(blocks[np.tril(~present)] == 0.0)  # what is not stored is exactly zero in the dense S
+        assert np.abs(got - oS[6 * j: 6 * j + 6, 6 * k: 6 * k + 6]).max() <= 1e-11 * scale, ("oracle", j, k)
+        assert np.abs(got - S[6 * j: 6 * j + 6, 6 * k: 6 * k + 6]).max() <= 1e-11 * scale, ("dense route", j, k)
+    # what is not stored is exactly zero in the oracle's S (and in the dense route's)
+    for full in (oS, S):
+        blocks = np.abs(full.reshape(n_cams, 6, n_cams, 6)).max(axis=(1, 3))
+        assert np.all(blocks[np.tril(~present)] == 0.0)
+    assert np.abs(ea_s - oea).max() <= 1e-10 * np.abs(oea).max()
     assert np.abs(ea_s - ea).max() <= 1e-10 * np.abs(ea).max()
     h.schur_reduce()
     h.schur_solve()
@@ -422,10 +445,13 @@ def test_block_sparse_S_and_pcg(n_cams, window):
     sc = h.backsub(mu)
     assert sc.status == 0
     dpa = h.get_dp()[:nA]
+    assert np.abs(dpa - odpa).max() <= 1e-8 * np.abs(odpa).max()       # the oracle's solve (LAPACK on its S at 1000)
     assert np.abs(dpa - dpa_ref).max() <= 1e-8 * np.abs(dpa_ref).max()
     assert abs(sc.new_cost - sc_ref.new_cost) <= 1e-9 * sc_ref.new_cost
     h.upload_problem(prob)
     res, _ = h.levmar(max_iter=6, tr_handoff=False)
+    if owant is not None:
+        assert res.iters == owant.iters and abs(res.final_err - owant.final_err) <= 1e-8 * owant.final_err
     assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-8 * want.final_err
     # the rank layout is part of the block list: it cannot change under an uploaded sparse problem
     with pytest.raises(capi.PsbaError):
@@ -450,12 +476,23 @@ def test_block_sparse_S_with_sharded_points():
     import psba_amd
     from psba_amd import capi
     import psba_amd.synth as synth
+    from oracle_lib import Oracle
     prob = synth.make_problem(n_cams=240, n_pts=3000, mean_track=4.0, seed=991, window=24)
+    # the judge of the sums is the oracle on the WHOLE problem, the single handle second
+    orc = Oracle(prob)
+    olin = orc.linearize()
+    omu = 1e-3 * olin["maxdiag"]
+    osch = orc.schur(olin, omu)
+    ost, odp, _ = orc.solve(olin, osch)
+    assert ost == 0.0
+    oS, oea = osch["S"], osch["eab"][: 6 * 240]
     ref = psba_amd.Psba(0)
     ref.set_solver(1, tol=1e-12, max_iter=2000)
     ref.upload_problem(prob)
     ref.linearize(1.0, 1.0)
     mu = 1e-3 * ref.max_diag()
+    assert abs(mu - omu) <= 1e-12 * omu
+    mu = omu
     ref.schur_assemble(mu); ref.schur_reduce()
     jk_ref, val_ref, ea_ref = ref.get_sparse_S()
     ref.schur_solve()
@@ -483,6 +520,13 @@ def test_block_sparse_S_with_sharded_points():
     val = sum(p[1] for p in parts)
     ea = sum(p[2] for p in parts)
     scale = np.abs(val_ref).max()
+    for (j, k), B in zip(jk_ref, val):
+        got = B if j != k else np.tril(B) + np.tril(B, -1).T
+        assert np.abs(got - oS[6 * j: 6 * j + 6, 6 * k: 6 * k + 6]).max() <= 1e-11 * scale, ("oracle", j, k)
+    stored = np.zeros((240, 240), dtype=bool)
+    stored[jk_ref[:, 0], jk_ref[:, 1]] = True
+    assert np.all(np.abs(oS.reshape(240, 6, 240, 6)).max(axis=(1, 3))[np.tril(~stored)] == 0.0)
+    assert np.abs(ea - oea).max() <= 1e-10 * np.abs(oea).max()
     assert np.abs(val - val_ref).max() <= 1e-11 * scale
     assert np.abs(ea - ea_ref).max() <= 1e-10 * np.abs(ea_ref).max()
     got = np.zeros(4)
@@ -490,6 +534,7 @@ def test_block_sparse_S_with_sharded_points():
         h.set_sparse_S(val, ea)
         h.schur_solve()
         dpa = h.get_dp()[: 6 * 240]
+        assert np.abs(dpa - odp[: 6 * 240]).max() <= 1e-8 * np.abs(odp[: 6 * 240]).max()
         assert np.abs(dpa - dpa_ref).max() <= 1e-8 * np.abs(dpa_ref).max()
         sc = h.backsub(mu)
         assert sc.status == 0
@@ -498,6 +543,80 @@ def test_block_sparse_S_with_sharded_points():
         assert abs(g - w) <= 1e-8 * abs(w), (g, w)
     for h in hs + [ref]:
         h.close()
+
+
+def test_pcg_stop_conditions():
+    """ADVICE r3 (kernels_pcg.hip): (1) e_a == 0 -- and any exactly solved system -- is a converged solve,
+    not a break-down (p.Sp = 0 there used to be stamped PSBA_NOT_SPD and the LM loop raised mu); (2) a
+    solve that uses up max_iter says so (PSBA_PCG_MAXIT from psba_schur_solve, counted by psba_levmar)
+    instead of passing for converged; (3) the device stops iterating inside a burst of eight once the
+    residual test holds, and the iterate it keeps is the one that passed the test (true residual
+    against the oracle's S)."""
+    import psba_amd
+    import psba_amd.synth as synth
+    from oracle_lib import Oracle
+    n_cams = 60
+    prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=4242, window=20)
+    nA = 6 * n_cams
+    orc = Oracle(prob)
+    olin = orc.linearize()
+    mu = 1e-3 * olin["maxdiag"]
+    osch = orc.schur(olin, mu)
+    oS, oea = osch["S"], osch["eab"][:nA]
+
+    def assembled(tol, max_iter):
+        h = psba_amd.Psba(0)
+        h.set_solver(1, tol=tol, max_iter=max_iter)
+        h.upload_problem(prob)
+        h.linearize(1.0, 1.0)
+        h.schur_assemble(mu)
+        return h
+
+    # (1) zero right-hand side
+    h = assembled(1e-12, 500)
+    _, val, _ = h.get_sparse_S()
+    h.set_sparse_S(val, np.zeros(nA))
+    assert h.schur_solve() == 0
+    iters, relres, _, _ = h.pcg_info()
+    assert iters == 0 and relres == 0.0
+    sc = h.backsub(mu)
+    assert not (sc.status & 1), "a zero right-hand side is not a failed factorization"
+    assert np.all(h.get_dp()[:nA] == 0.0)
+    h.close()
+
+    # (2) max_iter exhausted
+    h = assembled(1e-14, 3)
+    assert h.schur_solve() == 4  # PSBA_PCG_MAXIT
+    iters, relres, _, _ = h.pcg_info()
+    assert iters == 3 and relres > 1e-14
+    x = h.get_dp()[:nA]
+    true_rel = np.linalg.norm(oS @ x - oea) / np.linalg.norm(oea)
+    assert abs(true_rel - relres) <= 1e-6 * relres + 1e-12   # the reported residual is the iterate's
+    sc = h.backsub(mu)
+    assert not (sc.status & 1)
+    h.upload_problem(prob)
+    res, _ = h.levmar(max_iter=3, tr_handoff=False)
+    assert res.pcg_unconverged >= 3
+    h.close()
+
+    # (3) convergence inside a burst: the loose tolerance is met after a few iterations
+    h = assembled(1e-3, 500)
+    assert h.schur_solve() == 0
+    iters, relres, _, _ = h.pcg_info()
+    assert 0 < iters < 500 and relres <= 1e-3
+    x = h.get_dp()[:nA]
+    true_rel = np.linalg.norm(oS @ x - oea) / np.linalg.norm(oea)
+    assert true_rel <= 1.01e-3 and abs(true_rel - relres) <= 1e-6
+    # one iteration fewer does not pass the test: the device stopped at the first iteration that did
+    h2 = assembled(1e-3, iters - 1) if iters > 1 else None
+    if h2 is not None:
+        assert h2.schur_solve() == 4
+        assert h2.pcg_info()[1] > 1e-3
+        h2.close()
+    h.upload_problem(prob)
+    res, _ = h.levmar(max_iter=4, tr_handoff=False)
+    assert res.pcg_unconverged == 0
+    h.close()
 
 
 def test_sharded_dense_factorization_emulated_with_three_handles():

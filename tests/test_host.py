@@ -416,3 +416,65 @@ def test_owner_plan_lists_every_product_once(n_cams, window):
         pat[j * (j + 1) // 2 + k] = 1
     pl2 = capi.owner_plan(prob["nC"], prob["nP"], ii, jj, pattern=pat)
     assert set(tuple(x) for x in pl2["blocks"]) == present | set(extra)
+
+
+def _run_bench(extra_env, *argv, timeout=240):
+    import subprocess, sys
+    env = dict(os.environ, PSBA_BENCH_STUB="1", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` (no launcher, no WORLD_SIZE) must start: the parent
+    spawns N fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set -- before importing
+    the library or touching a GPU -- waits, and relays rank 0's single JSON line.  The GPU work is replaced
+    by the stub (PSBA_BENCH_STUB=1: rendezvous, barrier and max-over-ranks still run, over gloo)."""
+    import json
+    out = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout          # exactly one line on stdout, and it is JSON
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "strong"             # the default: ONE problem split over the ranks (configs[3])
+    seen = sorted(tuple(x) for x in d["ranks_seen"])
+    assert [s[0] for s in seen] == [0, 1] and [s[1] for s in seen] == [0, 1]  # distinct RANK / LOCAL_RANK
+    assert seen[0][2] != seen[1][2]                                           # two processes
+    assert abs(d["max_over_ranks"] - 0.002) < 1e-12                           # the MAX over ranks reached rank 0
+    assert "rank 1 says hello" in out.stderr and "rank 1 says hello" not in out.stdout
+    assert "stray line" in out.stderr           # anything else rank 0 printed went to stderr
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    out = _run_bench({"PSBA_BENCH_STUB_FAIL_RANK": "1"}, "--gpus", "2")
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.strip()]  # no JSON line from a failed job
+    out = _run_bench({"PSBA_BENCH_STUB_FAIL_RANK": "0"}, "--gpus", "2")
+    assert out.returncode != 0
+
+
+def test_bench_parent_does_not_load_the_gpu_library():
+    """The spawning parent must not have initialised a GPU runtime: bench.py imports psba_amd (which dlopens
+    the HIP library) only in load_library(), which the spawn path never reaches."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    top = src.split("def load_library")[0]
+    assert "import psba_amd" not in top and "import torch" not in top
+    main_src = src.split("def main():")[1]
+    assert main_src.index("spawn_ranks(") < main_src.index("load_library()")
+
+
+def test_bench_collective_bytes():
+    """0.41 MB all-reduce at 52 cameras, 0.58 GB at cfg5 (packed lower block triangle)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.collective_bytes(52, 1, False)["allreduce_S_ea"] == 0
+    v = b.collective_bytes(52, 4, False)
+    assert v["allreduce_S_ea"] == 1378 * 288 and v["broadcast_factor_columns"] == 0
+    c = b.collective_bytes(2000, 8, True)
+    assert abs(c["allreduce_S_ea"] / 1e9 - 0.576) < 0.001
+    assert abs(c["broadcast_factor_columns"] / 1e9 - 0.576) < 0.001
