@@ -413,7 +413,10 @@ int psba_owner_plan_info(psba_owner_plan_t p, long long info[4]);
 int psba_owner_plan_copy(psba_owner_plan_t p, long long *waves, int *units, int *prod, int *blocks, int *diag_slot);
 void psba_owner_plan_destroy(psba_owner_plan_t p);
 
-/* ---- test hook: the schedule of the S-assembly kernel's ring route (few cameras), host only ----
+#ifdef PSBA_BUILD_EXPERIMENTS
+/* (Only in a library built with PSBA_BUILD_EXPERIMENTS=1: round 3's ring route is an experiment that lost,
+ * DESIGN 5c, and is not part of the product library.)
+ * ---- test hook: the schedule of the S-assembly kernel's ring route (few cameras), host only ----
  * The lower block triangle of S (reference CL_files/compute_S.cl:6-78) is cut into nR ranges of the
  * canonical block order and the point sequence into nS stretches; a workgroup per (range, stretch)
  * replays per-step lists: which runs of W records (up to 7, contiguous in W) are loaded into
@@ -438,6 +441,7 @@ int psba_ring_plan_info(psba_ring_plan_t p, long long info[16]);
 int psba_ring_plan_copy(psba_ring_plan_t p, long long *wg, int *steps, unsigned *entries, int *ops,
                         int *jobs, int *lane_blk, int *blk_lane0, int *rb);
 void psba_ring_plan_destroy(psba_ring_plan_t p);
+#endif /* PSBA_BUILD_EXPERIMENTS */
 
 #ifdef __cplusplus
 }

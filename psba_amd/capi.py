@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "libpsba_hip.so")
+# PSBA_LIB: another build of the library (psba_amd/libpsba_hip_exp.so = PSBA_BUILD_EXPERIMENTS=1 python psba_amd/build.py)
+lib_path = os.environ.get("PSBA_LIB") or os.path.join(_HERE, "libpsba_hip.so")
 
 if not os.path.exists(lib_path):
     raise ImportError(
@@ -152,12 +153,16 @@ SIGNATURES = [
     ("psba_owner_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_owner_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _ip, _ip, _ip, _ip]),
     ("psba_owner_plan_destroy", None, [C.c_void_p]),
+]
+# only in a library built with PSBA_BUILD_EXPERIMENTS=1 (round 3's rejected ring route and its test hooks)
+EXPERIMENT_SIGNATURES = [
     ("psba_ring_plan_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     ("psba_ring_plan_info", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("psba_ring_plan_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _ip, C.POINTER(C.c_uint), _ip, _ip, _ip, _ip, _ip]),
     ("psba_ring_plan_destroy", None, [C.c_void_p]),
 ]
-for _name, _res, _args in SIGNATURES:
+HAS_EXPERIMENTS = hasattr(lib, "psba_ring_plan_create")
+for _name, _res, _args in SIGNATURES + (EXPERIMENT_SIGNATURES if HAS_EXPERIMENTS else []):
     _f = getattr(lib, _name)
     _f.restype = _res
     _f.argtypes = _args
@@ -297,7 +302,9 @@ def owner_plan(n_cams, n_pts, iidx, jidx, pattern=None):
 def ring_plan(n_cams, n_pts, iidx, jidx):
     """The schedule of the S-assembly kernel's ring route for a sparsity pattern (host only, no
     device): dict of the arrays psba_ring_plan_copy documents, or None when the route does not
-    apply to the problem."""
+    apply to the problem.  Needs a library built with PSBA_BUILD_EXPERIMENTS=1."""
+    if not HAS_EXPERIMENTS:
+        raise PsbaError(-6, "the ring route is an experiment: build with PSBA_BUILD_EXPERIMENTS=1")
     iidx = _c(iidx, np.int32)
     jidx = _c(jidx, np.int32)
     p = lib.psba_ring_plan_create(int(n_cams), int(n_pts), int(iidx.size), _i(iidx), _i(jidx))

@@ -8,6 +8,14 @@
 
 namespace psba {
 
+// F32_EXP: bit mask of timing-only experiments (scripts/ubench_f32.hip defines it; the product never does):
+// 1 the pivot wave does not wait for staged panels, 2 it skips the previous panel's rank-4 update,
+// 4 it does not publish 1/d and d.  Wrong numbers, right costs.
+#ifndef F32_EXP
+#define F32_EXP 0
+#endif
+
+
 constexpr int GB = 32;  // panel width
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) int lds_int;
@@ -40,21 +48,25 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 //   wave 2  tile wave: keeps the trailing matrix as three 16x16 tiles in the MFMA accumulator
 //           layout, applies each published panel as one v_mfma_f64_16x16x4_f64 per tile and
 //           stages the columns of panel p+2 (updates <= p applied) for the pivot wave;
-//   wave 1  inverse of the upper-left 16x16 of the eliminated columns, column c per lane, rows
-//           following the panels as they are published; then T = D21 inv(D11) by MFMA;
-//   wave 3  inverse of the lower-right 16x16 the same way, then inv21 = -inv(D22) T by MFMA.
+//   wave 1  inverse of the 32x32 triangular factor, column c per lane pair (lanes c and c + 32 share a
+//           column and split every row's sum), rows following the panels as they are published: what a
+//           row takes from earlier panels' columns is summed before its own panel arrives, so the wave
+//           ends a handful of dependent operations behind the pivot wave;
+//   wave 3  square roots of the pivots and the failure flag, once the last panel is out.
 // The square roots are taken once at the end, 32 lanes in parallel: L^-1 = diag(sqrt d) D^-1.
 // Progress is published through LDS words (one writer each): sFlag[0] = panels in sD,
-// sFlag[1] = panels staged by the tile wave (+2), sFlag[2] = tile wave has loaded its tiles,
-// sFlag[3] = T is in LDS.  A wave's LDS operations complete in order, so data written before a
+// sFlag[1] = panels staged by the tile wave (+2), sFlag[2] = tile wave has loaded its tiles.
+// A wave's LDS operations complete in order, so data written before a
 // flag is visible to whoever sees the flag.  No wave exits early, so every wait ends.
+// (Until round 4 two waves inverted the two 16x16 diagonal blocks and combined them by two chained MFMA
+// products after the last panel: 1100 cycles behind the pivot wave; scripts/ubench_f32.hip.)
 struct Factor32Lds {
   // in: the block (lower triangle valid); out: the columns of its LDL^T-style elimination,
   // D[r][c] = L[r][c] sqrt(d_c) with d_c = D[c][c] the pivots (zeros above the diagonal)
   double D[GB][GB + 1];
   double Li[GB][GB + 1];  // out: inverse of D as a matrix (lower triangle valid)
   double next[2][GB][4];  // staged panels
-  double rinv[GB];        // 1 / d_c
+  alignas(32) double rinv[GB];  // 1 / d_c (written four at a time)
   double sq[GB];          // sqrt(d_c): L = D diag(1 / sq), L^-1 = diag(sq) Li
   int flag[4];
   int fail;
@@ -89,15 +101,15 @@ __device__ __forceinline__ double recip_cubic(double d) {
 // columns are published unmasked (what lands above the diagonal only ever reaches dead entries:
 // the consumers read the lower triangle, and as MFMA operands those values only touch rows /
 // columns that are already final), and 1/d, d are stored once per panel.
-__device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long long *tim = nullptr) {
+template <bool TIMED>
+__device__ __forceinline__ void f32_pivot_wave(Factor32Lds &s, int lane, long long *tim) {
   const int row = lane & 31;
-  bool bad = false;
   d4 a, tp = {0, 0, 0, 0};  // this panel's columns; the previous panel's divided by their pivots
 #pragma clang loop unroll(full)
   for (int q = 0; q < 8; q++) {
     const int j0 = 4 * q;
     double sc[4][4];  // the previous panel's entries in this panel's four pivot rows
-    if (q > 0) {
+    if (q > 0 && !(F32_EXP & 2)) {
 #pragma unroll
       for (int k2 = 0; k2 < 4; k2++)
 #pragma unroll
@@ -114,26 +126,35 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
         f = *(volatile lds_int *)&s.flag[1];
 #pragma unroll
         for (int k = 0; k < 4; k++) a[k] = *(volatile lds_double *)&s.next[q & 1][row][k];
-      } while (f < q - 1);
+      } while (f < q - 1 && !(F32_EXP & 1));
     }
-    if (q > 0) {  // rank-4 update by the previous panel, in the row layout
+    if (q > 0 && !(F32_EXP & 2)) {  // rank-4 update by the previous panel, in the row layout
 #pragma clang loop unroll(full)
       for (int k2 = 0; k2 < 4; k2++)
 #pragma clang loop unroll(full)
         for (int k = 0; k < 4; k++) a[k2] -= tp[k] * sc[k2][k];
     }
-    d4 t, rr, dd;
+    d4 t, rr;
     double d = readlane_f64g(a[0], j0);
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; k++) {
-      bad |= !(d > 0.0);  // also NaN; an infinite pivot ends in a non-finite solution, caught there
-      const double r = recip_cubic(d);
-      t[k] = a[k] * r;
-      rr[k] = r;
-      dd[k] = d;  // the square root is taken at the end, off the chain
+      // (a pivot that is not positive -- or NaN -- shows in its reciprocal: wave 3 looks at those at the end)
+      // 1 / d = r0 (1 + p), p = e + e^2, e = 1 - d r0 (v_rcp_f64 is good to ~2^-24; the cubic step finishes it).
+      // Only p sits on the way to the next pivot: the column divided by the seed (u), its product with the
+      // column (v) and a[k+1] - u a[k] (m) are formed beside e and p, and the next pivot is m - v p in its own
+      // lane -- rcp + three dependent operations from pivot to pivot instead of rcp + five
+      const double r0 = __builtin_amdgcn_rcp(d);
+      const double e = __builtin_fma(-d, r0, 1.0);
+      const double u = a[k] * r0;
+      const double pp = __builtin_fma(e, e, e);
       if (k < 3) {
-        // the next pivot, in its own lane: no broadcast between two pivots but the pivot itself
-        d = readlane_f64g(__builtin_fma(-t[k], a[k], a[k + 1]), j0 + k + 1);
+        const double v = u * a[k];
+        const double m = __builtin_fma(-u, a[k], a[k + 1]);
+        d = readlane_f64g(__builtin_fma(-v, pp, m), j0 + k + 1);
+      }
+      t[k] = __builtin_fma(u, pp, u);    // a[k] / d
+      rr[k] = __builtin_fma(r0, pp, r0);  // 1 / d
+      if (k < 3) {
 #pragma clang loop unroll(full)
         for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= t[k] * readlane_f64g(a[k], j0 + k2);
       }
@@ -143,18 +164,21 @@ __device__ __forceinline__ bool f32_pivot_wave(Factor32Lds &s, int lane, long lo
     if (q == 2) f32_wait(&s.flag[2], 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) s.D[row][j0 + k] = a[k];  // lanes 32..63 repeat lanes 0..31
+    // lane 0: the reciprocals, then the flag (in this order: a wave's LDS operations execute in order; the
+    // pivots themselves are the diagonal of what was just published)
+    asm volatile("" ::: "memory");
     if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        s.rinv[j0 + k] = rr[k];
-        s.sq[j0 + k] = dd[k];
-      }
+      if (!(F32_EXP & 4)) *reinterpret_cast<d4 *>(&s.rinv[j0]) = rr;
+      *(volatile lds_int *)&s.flag[0] = q + 1;
     }
-    f32_post(&s.flag[0], q + 1, lane);
+    asm volatile("" ::: "memory");
     tp = t;
-    if (tim && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
+    if (TIMED && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
   }
-  return bad;
+  // (measured and dropped, scripts/ubench_f32.hip: the next panel's staged columns fetched one to three pivots
+  // ahead and its first pivot formed from the lane's own values before the general update -- the LDS round
+  // trip of the sixteen scalars stays on the way to the second pivot, and the extra instructions cost more
+  // than the first pivot gains: 810 -> 930 cycles per panel)
 }
 
 __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
@@ -204,81 +228,79 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
   }
 }
 
-// rows [o, o+16) of the inverse of the diagonal 16x16 block of D at (o, o): lane c owns column o + c
-template <int O>
-__device__ __forceinline__ d16 f32_inverse16(Factor32Lds &s, int lane) {
-  const int c = lane & 15;
-  d16 x;
+// Inverse of the eliminated columns D as a lower-triangular matrix X (X D = I), one wave, on the matrix
+// pipe, four rows per published panel.  With P the panel's rows and the rows above it done,
+//     X[P, :] = inv(D_PP) (E_P - ACC[P, :]),     ACC[r, :] = sum over earlier panels Q of D[r, Q] X[Q, :].
+// ACC is kept as three 16x16 accumulator tiles (rows 0-15 x columns 0-15, rows 16-31 x both column halves)
+// and grows by one v_mfma_f64_16x16x4_f64 per tile and panel (A = the panel's four columns of D, B = the
+// four new rows of X: the accumulator layout of rows 4p .. 4p+3 -- register p mod 4 of lane group k -- IS
+// the B layout, so nothing is transposed).  inv(D_PP) of the 4x4 triangle is formed entry by entry in the
+// lane that holds it as an A operand: D_PP = (I + N) diag(d) with N strictly lower and N^4 = 0, so
+// inv(D_PP) = diag(1/d) (I - N + N^2 - N^3): at most four products per entry.  After the last panel the wave
+// is one batch of LDS reads, ~10 dependent operations and one MFMA behind the pivot wave (the two-wave
+// scheme it replaces finished with two chained 16x16x16 products: 1100 cycles; scripts/ubench_f32.hip).
+// Entries of D above the diagonal are never-initialised LDS (see f32_pivot_wave): they are selected away,
+// never multiplied by zero, and as MFMA operands they only reach rows of ACC that are no longer read.
+__device__ __forceinline__ void f32_inverse_mfma(Factor32Lds &s, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  const int i = li & 3, k = lk;                       // entry (i, k) of the 4x4 operand (lanes li >= 4: zero rows)
+  const int j1 = k + 1 < 3 ? k + 1 : 3, j2 = k + 2 < 3 ? k + 2 : 3;
+  const bool lower = li < 4 && i > k, two = li < 4 && i - k >= 2, three = li < 4 && i - k == 3;
+  d4 acc00 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const d4 zero = {0, 0, 0, 0};
 #pragma clang loop unroll(full)
-  for (int p = 0; p < 4; p++) {
-    f32_wait(&s.flag[0], O / 4 + p + 1);
-#pragma clang loop unroll(full)
-    for (int k = 0; k < 4; k++) {
-      const int r = 4 * p + k;
-      // four partial sums: the wave runs alone on its SIMD, so a single chain of up to 15
-      // dependent fma would cost ~16 cycles a link, most of it in the tail behind the pivot wave
-      double sm[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma clang loop unroll(full)
-      for (int m = 0; m < r; m++) sm[m & 3] += s.D[O + r][O + m] * x[m];
-      const double v = ((r == c) ? 1.0 : 0.0) - ((sm[0] + sm[1]) + (sm[2] + sm[3]));
-      const double xr = v * s.rinv[O + r];  // 1 / D[r][r]
-      x[r] = xr;
-      // pin the row here: otherwise the compiler sinks the arithmetic below the last wait and
-      // keeps every L value read so far in registers
-      asm volatile("" ::"v"(xr));
+  for (int p = 0; p < 8; p++) {
+    const int j0 = 4 * p;
+    f32_wait(&s.flag[0], p + 1);
+    const double dik = s.D[j0 + i][j0 + k], dij1 = s.D[j0 + i][j0 + j1], dj1k = s.D[j0 + j1][j0 + k];
+    const double dij2 = s.D[j0 + i][j0 + j2], dj2k = s.D[j0 + j2][j0 + k], dj2j1 = s.D[j0 + j2][j0 + j1];
+    const double rk = s.rinv[j0 + k], rj1 = s.rinv[j0 + j1], rj2 = s.rinv[j0 + j2], ri = s.rinv[j0 + i];
+    const double a0 = p < 4 ? s.D[li][j0 + lk] : 0.0, a1 = s.D[16 + li][j0 + lk];  // the panel's columns, both row blocks
+    // N = D_PP diag(1/d) - I;  (I - N + N^2 - N^3)[i][k] for i > k
+    const double nik = lower ? dik * rk : 0.0, nj1k = dj1k * rk;
+    const double nij1 = two ? dij1 * rj1 : 0.0, nij2 = three ? dij2 * rj2 : 0.0;
+    const double nj2k = dj2k * rk, nj2j1 = dj2j1 * rj1;
+    double m = -nik + nij1 * nj1k + nij2 * (nj2k - nj2j1 * nj1k);
+    m = (li < 4 && i == k) ? 1.0 : m;
+    const double A = ri * m;  // inv(D_PP)[i][k] (zero above the diagonal and in the padding rows)
+    // right-hand sides: delta - ACC in the rows of this panel (register p mod 4), per column half
+    const double dl = (j0 + lk == li) ? 1.0 : 0.0, dr = (j0 + lk == 16 + li) ? 1.0 : 0.0;
+    const double rhs0 = p < 4 ? dl - acc00[p & 3] : -acc10[p & 3];
+    const d4 x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A, rhs0, zero, 0, 0, 0);
+    d4 x1 = zero;
+    if (p >= 4) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A, dr - acc11[p & 3], zero, 0, 0, 0);
+    s.Li[j0 + lk][li] = x0[0];
+    s.Li[j0 + lk][16 + li] = x1[0];  // zero for the rows of the upper block: Li is read as a full 32x32
+    if (p < 7) {
+      if (p < 4) acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x0[0], acc00, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x0[0], acc10, 0, 0, 0);
+      if (p >= 4) acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x1[0], acc11, 0, 0, 0);
     }
   }
-  if (lane < 16) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) s.Li[O + r][O + c] = x[r];
-  }
-  return x;
-}
-
-// 16x16x16 product of two LDS-resident blocks in the MFMA operand layouts: A[i][k] at
-// pa[i * lda + k], B[k][j] at pb[k * ldb + j]
-__device__ __forceinline__ d4 f32_mm16(const double *pa, int lda, const double *pb, int ldb, int lane) {
-  const int li = lane & 15, lk = lane >> 4;
-  d4 acc = {0, 0, 0, 0};
-#pragma unroll
-  for (int t = 0; t < 4; t++)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[li * lda + 4 * t + lk], pb[(4 * t + lk) * ldb + li], acc, 0, 0, 0);
-  return acc;
 }
 
 // Factor the 32x32 block held in s.D (lower triangle valid) and invert the factor into s.Li.
 // The caller has zeroed s.flag[] / s.fail and synchronised; needs waves 0..3 of the workgroup.
+template <bool TIMED = false>
 __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 15, rc = lane >> 4;
   if (wave == 0) {
-    if (f32_pivot_wave(s, lane, tim)) s.fail = 1;
-    if (tim && lane == 0) tim[3] = (long long)__builtin_amdgcn_s_memtime();
+    f32_pivot_wave<TIMED>(s, lane, tim);
+    if (TIMED && lane == 0) tim[3] = (long long)__builtin_amdgcn_s_memtime();
   } else if (wave == 2) {
     f32_tile_wave(s, lane);
   } else if (wave == 1) {
-    f32_inverse16<0>(s, lane);
-    // T = L21 inv(L11) into the (otherwise unused) upper-right quadrant of Li
-    f32_wait(&s.flag[0], 4);
-    const d4 t = f32_mm16(&s.D[16][0], GB + 1, &s.Li[0][0], GB + 1, lane);
-#pragma unroll
-    for (int r = 0; r < 4; r++) s.Li[rc + 4 * r][16 + col] = t[r];
-    f32_post(&s.flag[3], 1, lane);
+    f32_inverse_mfma(s, lane);
+    if (TIMED && lane == 0) tim[4] = (long long)__builtin_amdgcn_s_memtime();
   } else if (wave == 3) {
-    f32_inverse16<16>(s, lane);
-    f32_wait(&s.flag[3], 1);
-    const d4 t = f32_mm16(&s.Li[16][16], GB + 1, &s.Li[0][16], GB + 1, lane);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      s.Li[16 + rc + 4 * r][col] = -t[r];
-      s.Li[rc + 4 * r][16 + col] = 0.0;  // T is consumed: Li is read as a full 32x32 by the trsm
+    // the square roots of the pivots (the diagonal of the published columns) and the verdict: a pivot
+    // that was not positive (or not a number) leaves a reciprocal that is not a positive finite number
+    f32_wait(&s.flag[0], 8);
+    if (lane < GB) {
+      const double d = s.D[lane][lane], r = s.rinv[lane];
+      s.sq[lane] = d * rsqrt_nr(d);
+      if (!(r > 0.0) || !(r < __builtin_huge_val())) s.fail = 1;
     }
-    if (tim && lane == 0) tim[4] = (long long)__builtin_amdgcn_s_memtime();
-  }
-  __syncthreads();
-  if (tid < GB) {  // sq held the pivots so far
-    const double d = s.sq[tid];
-    s.sq[tid] = d * rsqrt_nr(d);
   }
   __syncthreads();
 }

@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void k_cholg_diag(const double *Lw, double *Lx
   stage_block32(s.D, Lw + (size_t)j * ld + j, (size_t)ld, tid);
   __syncthreads();
   if (tim && tid == 0) tim[1] = (long long)__builtin_amdgcn_s_memtime();
-  factor32(s, tid, tim);
+  if (tim)
+    factor32<true>(s, tid, tim);
+  else
+    factor32<false>(s, tid);
   if (tim && tid == 0) tim[2] = (long long)__builtin_amdgcn_s_memtime();
   double *li = linv + (size_t)(j / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {

@@ -858,7 +858,9 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
     if (dump) return fail(h, PSBA_E_INVALID, "the sba_func.h mirror verbs need the dense S: PSBA_SOLVER_DENSE");
     return launch_schur_sparse(h, mu);
   }
+#ifdef PSBA_BUILD_EXPERIMENTS
   if (h->ring_nWg > 0 && !getenv("PSBA_SCHUR_ATOMIC")) return launch_schur_ring(h, mu, dump);
+#endif
   if (h->nGroups > 0 && !getenv("PSBA_SCHUR_ATOMIC")) {
     if (!h->lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition

@@ -139,6 +139,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->diag0);
   dev_free(h->redp);
   dev_free(h->slab);
+#ifdef PSBA_BUILD_EXPERIMENTS
   dev_free(h->ring_wg);
   dev_free(h->ring_steps);
   dev_free(h->ring_entries);
@@ -148,6 +149,7 @@ static void free_problem_buffers(psba_ctx *h) {
   dev_free(h->ring_canon);
   dev_free(h->ring_slab);
   dev_free(h->ring_pvi);
+#endif
   h->ring_nWg = h->ring_nS = 0;
   dev_free(h->bs_val);
   h->bs_ea = nullptr;
@@ -470,6 +472,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
               h->bs_nblk, (long long)nCams * (nCams + 1) / 2, 100.0 * (double)h->bs_nblk / ((double)nCams * (nCams + 1) / 2),
               op.products);
   }
+#ifdef PSBA_BUILD_EXPERIMENTS
   if (!sparse) {
     RingPlanHost rp;
     TRY(build_ring_plan(nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), rp));
@@ -512,6 +515,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       }
     }
   }
+#endif
   if (!sparse && !h->ring_nWg) {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
@@ -1651,6 +1655,7 @@ int psba_owner_plan_copy(psba_owner_plan_t p, long long *waves, int *units, int 
 
 void psba_owner_plan_destroy(psba_owner_plan_t p) { delete p; }
 
+#ifdef PSBA_BUILD_EXPERIMENTS
 // ---- test hook: the ring route's schedule (schur_ring_plan.cpp), host only ----
 struct psba_ring_plan {
   psba::RingPlanHost plan;
@@ -1727,5 +1732,6 @@ int psba_ring_plan_copy(psba_ring_plan_t p, long long *wg, int *steps, unsigned 
 }
 
 void psba_ring_plan_destroy(psba_ring_plan_t p) { delete p; }
+#endif  // PSBA_BUILD_EXPERIMENTS
 
 }  // extern "C"

@@ -87,7 +87,9 @@ struct OwnerPlanHost {
   std::vector<int> diag_slot;      // [nC] index of block (j, j) in `blocks`
   long long products = 0;
 };
-// ---- K2 ring route (few cameras): schur_ring_plan.cpp / kernels_schur_ring.hip ----
+#ifdef PSBA_BUILD_EXPERIMENTS
+// ---- K2 ring route (few cameras), an experiment of round 3 that lost: schur_ring_plan.cpp /
+// kernels_schur_ring.hip, compiled only with PSBA_BUILD_EXPERIMENTS=1 (psba_amd/build.py) ----
 constexpr int RING_LANES = 256;      // consumer lanes of a workgroup (4 waves); every lane owns one 6x6 block
 constexpr int RING_MOVERS = 4;       // waves that stream W records into the LDS ring with LDS-DMA
 constexpr int RING_PREPPERS = 4;     // waves that form Y_a = W_a V*^-1 (two lanes per job)
@@ -121,6 +123,7 @@ struct RingPlanHost {
   std::vector<int> blk_lane0;       // [wg][nblk + 1] first lane of each local block
   long long products = 0, slots = 0, loaded_recs = 0;
 };
+#endif  // PSBA_BUILD_EXPERIMENTS
 struct SchurPlanHost {
   std::vector<unsigned long long> items;
   std::vector<SchurWg> wgs;
@@ -206,8 +209,9 @@ struct psba_ctx {
   int *posblock = nullptr;      // per group, per partition position: (j << 16) | k of the block there, -1 = padding
   double *slab = nullptr;       // per workgroup: its group's partition, 36 doubles per position
   size_t packedN = 0;           // 36 * nC (nC+1) / 2 doubles: packed lower block triangle of S
+  int ring_nWg = 0, ring_nS = 0;  // (workgroups of the experimental ring route; 0 in the product build)
+#ifdef PSBA_BUILD_EXPERIMENTS
   // K2 ring route (few cameras): see RingPlanHost
-  int ring_nWg = 0, ring_nS = 0;
   psba::RingWg *ring_wg = nullptr;
   psba::RingStep *ring_steps = nullptr;
   unsigned *ring_entries = nullptr;
@@ -221,6 +225,7 @@ struct psba_ctx {
   size_t ring_loaded_recs = 0;
   bool ring_attr_set = false;
   long long *chol_tim_ring = nullptr;  // dev instrumentation (PSBA_RING_TIMING): per-step s_memtime stamps of two workgroups
+#endif
   // block-sparse S + preconditioned CG (psba_set_solver, kernels_pcg.hip)
   int solver = 0;               // PSBA_SOLVER_*
   double pcg_tol = 1e-10;
@@ -326,9 +331,11 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
 int build_owner_plan(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, OwnerPlanHost &out,
                      const unsigned char *pattern = nullptr);
 int sparse_pattern(int nCams, int nObs, const int *iidx, const int *jidx, const int *ptr, unsigned char *flags);
+#ifdef PSBA_BUILD_EXPERIMENTS
 int build_ring_plan(int nCams, int nPts, int nObs, const int *iidx, const int *jidx, const int *ptr, RingPlanHost &out,
                     bool force = false);
 int launch_schur_ring(psba_ctx *h, double mu, bool dump);
+#endif
 int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip

@@ -913,8 +913,12 @@ def test_ring_route_opt_in(name, problems, monkeypatch):
     LDS-DMA following a host-simulated schedule; built in round 3, measured slower than the
     LDS-partition route and therefore opt-in) must stay correct: the mirror verbs' Vinv / Y
     / S / ea against the oracle, the fused verb's reduce buffer, and a short LM run against the
-    default route."""
+    default route.  The route is not in the product library: PSBA_BUILD_EXPERIMENTS=1 python psba_amd/build.py
+    builds psba_amd/libpsba_hip_exp.so, PSBA_LIB points the binding at it."""
     import psba_amd
+    from psba_amd import capi
+    if not capi.HAS_EXPERIMENTS:
+        pytest.skip("experiment build only (PSBA_BUILD_EXPERIMENTS=1)")
     prob = problems[name]
     o = Oracle(prob)
     lin = o.linearize()

@@ -507,7 +507,7 @@ def test_garbage_step_through_the_lookahead_chain(problems, bad):
     assert not (new_cost < cost0)         # NaN or larger: never an improvement
     assert not (sc.new_cost < cost0)
     # the step is rejected: nothing of it may survive.  The plain loop from here equals a fresh handle's.
-    assert h.residual(0) == cost0
+    assert abs(h.residual(0) - cost0) <= 1e-13 * cost0   # (workgroup sums arrive in any order: rounding, not bits)
     res, _ = h.levmar(max_iter=6, tr_handoff=False)
     assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-12 * want.final_err
     h.close()

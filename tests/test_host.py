@@ -12,6 +12,7 @@ from conftest import DATA, ROOT
 def test_library_exports_every_declared_symbol():
     from psba_amd import capi
     hdr = open(os.path.join(ROOT, "include", "psba_hip.h")).read()
+    hdr = re.sub(r"#ifdef PSBA_BUILD_EXPERIMENTS.*?#endif /\* PSBA_BUILD_EXPERIMENTS \*/", "", hdr, flags=re.S)  # not in the product library
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(psba_[A-Za-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 40
@@ -227,13 +228,22 @@ def _replay_ring_plan(nC, nP, iidx, jidx, max_wgs=None):
     return plan
 
 
+def _needs_experiments():
+    from psba_amd import capi
+    if not capi.HAS_EXPERIMENTS:
+        pytest.skip("the ring route is an experiment (round 3, rejected): PSBA_BUILD_EXPERIMENTS=1 python psba_amd/build.py, "
+                    "then PSBA_LIB=psba_amd/libpsba_hip_exp.so")
+
+
 def test_ring_plan_small(problems):
+    _needs_experiments()
     for name in ("7cams", "54cams"):
         pr = problems[name]
         _replay_ring_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
 
 
 def test_ring_plan_venice_shaped():
+    _needs_experiments()
     from psba_amd import synth
     pr = synth.venice_shaped()
     plan = _replay_ring_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]), max_wgs=6)
