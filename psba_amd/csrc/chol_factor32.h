@@ -10,10 +10,11 @@ namespace psba {
 
 // F32_EXP: bit mask of timing-only experiments (scripts/ubench_f32.hip defines it; the product never does):
 // 1 the pivot wave does not wait for staged panels, 2 it skips the previous panel's rank-4 update,
-// 4 it does not publish 1/d and d.  Wrong numbers, right costs.
+// (4 was: it does not publish 1/d and d -- they are no longer published at all).  Wrong numbers, right costs.
 #ifndef F32_EXP
 #define F32_EXP 0
 #endif
+
 
 
 constexpr int GB = 32;  // panel width
@@ -64,10 +65,13 @@ struct Factor32Lds {
   // in: the block (lower triangle valid); out: the columns of its LDL^T-style elimination,
   // D[r][c] = L[r][c] sqrt(d_c) with d_c = D[c][c] the pivots (zeros above the diagonal)
   double D[GB][GB + 1];
-  double Li[GB][GB + 1];  // out: inverse of D as a matrix (lower triangle valid)
+  // out: Z = inverse of the UNIT lower factor T + I (T below the diagonal): D^-1 = diag(1 / d) Z, L^-1 = diag(sqrt d / d) Z
+  double Li[GB][GB + 1];
+  // the columns divided by their pivots, T[r][c] = D[r][c] / d_c (1 on the diagonal, never-initialised above): what
+  // the tile wave and the inverse wave multiply with -- nobody but the pivot wave ever needs a reciprocal
+  double T[GB][GB + 1];
   double next[2][GB][4];  // staged panels
-  alignas(32) double rinv[GB];  // 1 / d_c (written four at a time)
-  double sq[GB];          // sqrt(d_c): L = D diag(1 / sq), L^-1 = diag(sq) Li
+  double rsq[GB];         // 1 / sqrt(d_c): L = D diag(rsq), L^-1 = diag(rsq) Li   (the pivots d_c are the diagonal of D)
   int flag[4];
   int fail;
 };
@@ -134,11 +138,11 @@ __device__ __forceinline__ void f32_pivot_wave(Factor32Lds &s, int lane, long lo
 #pragma clang loop unroll(full)
         for (int k = 0; k < 4; k++) a[k2] -= tp[k] * sc[k2][k];
     }
-    d4 t, rr;
+    d4 t;
     double d = readlane_f64g(a[0], j0);
 #pragma clang loop unroll(full)
     for (int k = 0; k < 4; k++) {
-      // (a pivot that is not positive -- or NaN -- shows in its reciprocal: wave 3 looks at those at the end)
+      // (a pivot that is not positive -- or NaN -- stays on the diagonal: wave 3 looks at those at the end)
       // 1 / d = r0 (1 + p), p = e + e^2, e = 1 - d r0 (v_rcp_f64 is good to ~2^-24; the cubic step finishes it).
       // Only p sits on the way to the next pivot: the column divided by the seed (u), its product with the
       // column (v) and a[k+1] - u a[k] (m) are formed beside e and p, and the next pivot is m - v p in its own
@@ -153,7 +157,6 @@ __device__ __forceinline__ void f32_pivot_wave(Factor32Lds &s, int lane, long lo
         d = readlane_f64g(__builtin_fma(-v, pp, m), j0 + k + 1);
       }
       t[k] = __builtin_fma(u, pp, u);    // a[k] / d
-      rr[k] = __builtin_fma(r0, pp, r0);  // 1 / d
       if (k < 3) {
 #pragma clang loop unroll(full)
         for (int k2 = k + 1; k2 < 4; k2++) a[k2] -= t[k] * readlane_f64g(a[k], j0 + k2);
@@ -164,21 +167,23 @@ __device__ __forceinline__ void f32_pivot_wave(Factor32Lds &s, int lane, long lo
     if (q == 2) f32_wait(&s.flag[2], 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) s.D[row][j0 + k] = a[k];  // lanes 32..63 repeat lanes 0..31
-    // lane 0: the reciprocals, then the flag (in this order: a wave's LDS operations execute in order; the
-    // pivots themselves are the diagonal of what was just published)
-    asm volatile("" ::: "memory");
-    if (lane == 0) {
-      if (!(F32_EXP & 4)) *reinterpret_cast<d4 *>(&s.rinv[j0]) = rr;
-      *(volatile lds_int *)&s.flag[0] = q + 1;
-    }
-    asm volatile("" ::: "memory");
+    // the columns divided by their pivots: what the other waves multiply with, so that nobody else needs 1 / d
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.T[row][j0 + k] = t[k];
+    f32_post(&s.flag[0], q + 1, lane);
     tp = t;
     if (TIMED && lane == 0) tim[5 + q] = (long long)__builtin_amdgcn_s_memtime();
   }
-  // (measured and dropped, scripts/ubench_f32.hip: the next panel's staged columns fetched one to three pivots
-  // ahead and its first pivot formed from the lane's own values before the general update -- the LDS round
-  // trip of the sixteen scalars stays on the way to the second pivot, and the extra instructions cost more
-  // than the first pivot gains: 810 -> 930 cycles per panel)
+  // Measured on the way here (scripts/ubench_f32.hip, cycles per 4-column panel of this wave; round 3's code: 880):
+  //  * the pivot-to-pivot chain above instead of reciprocal -> column / d -> next pivot: 880 -> 810;
+  //  * 1 / d and d published by lane 0 (two 16-byte stores under an exec mask): ~100 of those 810; not publishing
+  //    them and letting the readers form 1 / d: 715, but the inverse wave (four reciprocals per panel) then falls
+  //    behind by 80 per panel; publishing the divided columns instead (this version): 790, nobody needs 1 / d;
+  //  * the same with the next panel's operands fetched between the two stores, or every column stored as soon as
+  //    it is final: 780 / 800, and a longer tail; the next panel's staged columns fetched one to three pivots ahead
+  //    and its first pivot formed from the lane's own values: 930.
+  // What is left is ~25 instructions per pivot issued by one wave: 4 x 130 cycles, + 170 for the rank-4 update
+  // with its LDS round trip, + 85 for the stores.
 }
 
 __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
@@ -198,19 +203,22 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
     // rank-4 update A -= (D / d) D^T: one operand scaled by 1 / d_k, k = this lane's k slot.
     // Flag and operands are read in one batch (volatile: issued in this order; a wave's LDS
     // reads complete in order), so a published panel costs one LDS round trip, not two
-    double a0 = 0.0, a1, nr;
+    double a0 = 0.0, t0 = 0.0, a1, t1;
     int f;
     do {
       f = *(volatile lds_int *)&s.flag[0];
       a1 = *(volatile lds_double *)&s.D[16 + col][j0 + rc];
-      nr = -*(volatile lds_double *)&s.rinv[j0 + rc];
-      if (p < 2) a0 = *(volatile lds_double *)&s.D[col][j0 + rc];
+      t1 = *(volatile lds_double *)&s.T[16 + col][j0 + rc];
+      if (p < 2) {
+        a0 = *(volatile lds_double *)&s.D[col][j0 + rc];
+        t0 = *(volatile lds_double *)&s.T[col][j0 + rc];
+      }
     } while (f < p + 1);
     if (p < 2) {  // columns < 16 are staged for panels 2, 3 only
-      T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * nr, a0, T00, 0, 0, 0);
-      T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * nr, a0, T10, 0, 0, 0);
+      T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-t0, a0, T00, 0, 0, 0);
+      T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-t1, a0, T10, 0, 0, 0);
     }
-    T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * nr, a1, T11, 0, 0, 0);
+    T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-t1, a1, T11, 0, 0, 0);
     const int j2 = j0 + 8;  // first column of panel p + 2
     if (j2 < 16) {
       if (col >= j2 && col < j2 + 4) {
@@ -228,20 +236,24 @@ __device__ __forceinline__ void f32_tile_wave(Factor32Lds &s, int lane) {
   }
 }
 
-// Inverse of the eliminated columns D as a lower-triangular matrix X (X D = I), one wave, on the matrix
-// pipe, four rows per published panel.  With P the panel's rows and the rows above it done,
-//     X[P, :] = inv(D_PP) (E_P - ACC[P, :]),     ACC[r, :] = sum over earlier panels Q of D[r, Q] X[Q, :].
+// Inverse of the unit lower factor, Z = (I + T)^-1 (T strictly lower: the eliminated columns divided by their
+// pivots), one wave, on the matrix pipe, four rows per published panel.  With P the panel's rows,
+//     Z[P, :] = inv(I + T_PP) (E_P - ACC[P, :]),     ACC[r, :] = sum over earlier panels Q of T[r, Q] Z[Q, :].
 // ACC is kept as three 16x16 accumulator tiles (rows 0-15 x columns 0-15, rows 16-31 x both column halves)
-// and grows by one v_mfma_f64_16x16x4_f64 per tile and panel (A = the panel's four columns of D, B = the
-// four new rows of X: the accumulator layout of rows 4p .. 4p+3 -- register p mod 4 of lane group k -- IS
-// the B layout, so nothing is transposed).  inv(D_PP) of the 4x4 triangle is formed entry by entry in the
-// lane that holds it as an A operand: D_PP = (I + N) diag(d) with N strictly lower and N^4 = 0, so
-// inv(D_PP) = diag(1/d) (I - N + N^2 - N^3): at most four products per entry.  After the last panel the wave
-// is one batch of LDS reads, ~10 dependent operations and one MFMA behind the pivot wave (the two-wave
-// scheme it replaces finished with two chained 16x16x16 products: 1100 cycles; scripts/ubench_f32.hip).
-// Entries of D above the diagonal are never-initialised LDS (see f32_pivot_wave): they are selected away,
+// and grows by one v_mfma_f64_16x16x4_f64 per tile and panel (A = the panel's four columns of T, B = the
+// four new rows of Z: the accumulator layout of rows 4p .. 4p+3 -- register p mod 4 of lane group k -- IS
+// the B layout, so nothing is transposed).  inv(I + N) of the 4x4 block (N = T_PP, N^4 = 0) is
+// I - N + N^2 - N^3, formed entry by entry in the lane that holds it as an A operand: at most four products.
+// Per panel the wave's dependent work is one batch of LDS reads, ~6 operations and two MFMAs; no reciprocal
+// anywhere (D^-1 = diag(1 / d) Z is never needed: L^-1 = diag(1 / sqrt d) Z, scaled when it is stored).
+// (History, scripts/ubench_f32.hip: two waves inverting the two 16x16 diagonal blocks of D row by row and
+// combining them with two chained 16x16x16 products finished 1100 cycles behind the pivot wave; this wave
+// working on D with the pivots' reciprocals read from LDS 520; with the reciprocals formed here it fell
+// behind by 80 cycles per panel.)
+// Entries of T above the diagonal are never-initialised LDS (see f32_pivot_wave): they are selected away,
 // never multiplied by zero, and as MFMA operands they only reach rows of ACC that are no longer read.
-__device__ __forceinline__ void f32_inverse_mfma(Factor32Lds &s, int lane) {
+template <bool TIMED = false>
+__device__ __forceinline__ void f32_inverse_mfma(Factor32Lds &s, int lane, long long *tim = nullptr) {
   const int li = lane & 15, lk = lane >> 4;
   const int i = li & 3, k = lk;                       // entry (i, k) of the 4x4 operand (lanes li >= 4: zero rows)
   const int j1 = k + 1 < 3 ? k + 1 : 3, j2 = k + 2 < 3 ? k + 2 : 3;
@@ -252,30 +264,28 @@ __device__ __forceinline__ void f32_inverse_mfma(Factor32Lds &s, int lane) {
   for (int p = 0; p < 8; p++) {
     const int j0 = 4 * p;
     f32_wait(&s.flag[0], p + 1);
-    const double dik = s.D[j0 + i][j0 + k], dij1 = s.D[j0 + i][j0 + j1], dj1k = s.D[j0 + j1][j0 + k];
-    const double dij2 = s.D[j0 + i][j0 + j2], dj2k = s.D[j0 + j2][j0 + k], dj2j1 = s.D[j0 + j2][j0 + j1];
-    const double rk = s.rinv[j0 + k], rj1 = s.rinv[j0 + j1], rj2 = s.rinv[j0 + j2], ri = s.rinv[j0 + i];
-    const double a0 = p < 4 ? s.D[li][j0 + lk] : 0.0, a1 = s.D[16 + li][j0 + lk];  // the panel's columns, both row blocks
-    // N = D_PP diag(1/d) - I;  (I - N + N^2 - N^3)[i][k] for i > k
-    const double nik = lower ? dik * rk : 0.0, nj1k = dj1k * rk;
-    const double nij1 = two ? dij1 * rj1 : 0.0, nij2 = three ? dij2 * rj2 : 0.0;
-    const double nj2k = dj2k * rk, nj2j1 = dj2j1 * rj1;
-    double m = -nik + nij1 * nj1k + nij2 * (nj2k - nj2j1 * nj1k);
-    m = (li < 4 && i == k) ? 1.0 : m;
-    const double A = ri * m;  // inv(D_PP)[i][k] (zero above the diagonal and in the padding rows)
+    if (TIMED && lane == 0) tim[16 + 2 * p] = (long long)__builtin_amdgcn_s_memtime();
+    const double tik = s.T[j0 + i][j0 + k], tij1 = s.T[j0 + i][j0 + j1], tj1k = s.T[j0 + j1][j0 + k];
+    const double tij2 = s.T[j0 + i][j0 + j2], tj2k = s.T[j0 + j2][j0 + k], tj2j1 = s.T[j0 + j2][j0 + j1];
+    const double a0 = p < 4 ? s.T[li][j0 + lk] : 0.0, a1 = s.T[16 + li][j0 + lk];  // the panel's columns, both row blocks
+    // (I - N + N^2 - N^3)[i][k] for i > k
+    const double nik = lower ? tik : 0.0, nij1 = two ? tij1 : 0.0, nij2 = three ? tij2 : 0.0;
+    double m = -nik + nij1 * tj1k + nij2 * (tj2k - tj2j1 * tj1k);
+    m = (li < 4 && i == k) ? 1.0 : m;  // (zero above the diagonal and in the padding rows)
     // right-hand sides: delta - ACC in the rows of this panel (register p mod 4), per column half
     const double dl = (j0 + lk == li) ? 1.0 : 0.0, dr = (j0 + lk == 16 + li) ? 1.0 : 0.0;
     const double rhs0 = p < 4 ? dl - acc00[p & 3] : -acc10[p & 3];
-    const d4 x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A, rhs0, zero, 0, 0, 0);
-    d4 x1 = zero;
-    if (p >= 4) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A, dr - acc11[p & 3], zero, 0, 0, 0);
-    s.Li[j0 + lk][li] = x0[0];
-    s.Li[j0 + lk][16 + li] = x1[0];  // zero for the rows of the upper block: Li is read as a full 32x32
+    const d4 z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, rhs0, zero, 0, 0, 0);
+    d4 z1 = zero;
+    if (p >= 4) z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, dr - acc11[p & 3], zero, 0, 0, 0);
     if (p < 7) {
-      if (p < 4) acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x0[0], acc00, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x0[0], acc10, 0, 0, 0);
-      if (p >= 4) acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x1[0], acc11, 0, 0, 0);
+      if (p < 4) acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, z0[0], acc00, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, z0[0], acc10, 0, 0, 0);
+      if (p >= 4) acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, z1[0], acc11, 0, 0, 0);
     }
+    s.Li[j0 + lk][li] = z0[0];
+    s.Li[j0 + lk][16 + li] = z1[0];  // zero for the rows of the upper block: Li is read as a full 32x32
+    if (TIMED && lane == 0) tim[17 + 2 * p] = (long long)__builtin_amdgcn_s_memtime();
   }
 }
 
@@ -290,16 +300,16 @@ __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim
   } else if (wave == 2) {
     f32_tile_wave(s, lane);
   } else if (wave == 1) {
-    f32_inverse_mfma(s, lane);
+    f32_inverse_mfma<TIMED>(s, lane, tim);
     if (TIMED && lane == 0) tim[4] = (long long)__builtin_amdgcn_s_memtime();
   } else if (wave == 3) {
-    // the square roots of the pivots (the diagonal of the published columns) and the verdict: a pivot
-    // that was not positive (or not a number) leaves a reciprocal that is not a positive finite number
+    // the square roots of the pivots (the diagonal of the published columns) and the verdict: every pivot
+    // positive and finite (a non-positive or NaN pivot stays where it is: the pivot wave only divides by it)
     f32_wait(&s.flag[0], 8);
     if (lane < GB) {
-      const double d = s.D[lane][lane], r = s.rinv[lane];
-      s.sq[lane] = d * rsqrt_nr(d);
-      if (!(r > 0.0) || !(r < __builtin_huge_val())) s.fail = 1;
+      const double d = s.D[lane][lane], y = rsqrt_nr(d);
+      s.rsq[lane] = y;
+      if (!(d > 0.0) || !(d < __builtin_huge_val())) s.fail = 1;
     }
   }
   __syncthreads();
@@ -307,10 +317,10 @@ __device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim
 
 // entry (r, c) of the Cholesky factor / of its inverse from what factor32 leaves in LDS
 __device__ __forceinline__ double f32_L(const Factor32Lds &s, int r, int c) {
-  return (c <= r) ? s.D[r][c] * (s.sq[c] * s.rinv[c]) : 0.0;  // 1 / sqrt(d) = sqrt(d) / d
+  return (c <= r) ? s.D[r][c] * s.rsq[c] : 0.0;
 }
 __device__ __forceinline__ double f32_Linv(const Factor32Lds &s, int r, int c) {
-  return (c <= r) ? s.Li[r][c] * s.sq[r] : 0.0;
+  return (c <= r) ? s.Li[r][c] * s.rsq[r] : 0.0;
 }
 
 }  // namespace psba

@@ -390,7 +390,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->chol_ws, (size_t)((d.nA + 31) / 32) * 1024));
   TRY(dev_alloc(h, &h->chol_L, dense));
   PSBA_HIP(h, hipMemsetAsync(h->chol_L, 0, sizeof(double) * dense, h->stream));
-  if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 16));
+  if (getenv("PSBA_CHOL_TIMING") && !h->chol_tim) TRY(dev_alloc(h, &h->chol_tim, 32));  // [0..15] diag kernel + pivot wave, [16..31] inverse wave
   // ---- K2's static schedule (groups of blocks, workgroups, conflict-free item rows) ----
   if (sparse) {
     // block-sparse S: the owner route's product lists give the blocks that exist

@@ -37,17 +37,21 @@ int main() {
       A[i * GB + j] = t;
     }
   double *dA, *dO;
-  long long *dT, hT[16];
-  hipMalloc(&dA, 8 * GB * GB); hipMalloc(&dO, 16 * GB * GB); hipMalloc(&dT, 16 * 8);
+  long long *dT, hT[32];
+  hipMalloc(&dA, 8 * GB * GB); hipMalloc(&dO, 16 * GB * GB); hipMalloc(&dT, 32 * 8);
   hipMemcpy(dA, A.data(), 8 * GB * GB, hipMemcpyHostToDevice);
   for (int rep = 0; rep < 3; rep++) {
-    hipMemset(dT, 0, 128);
+    hipMemset(dT, 0, 256);
     k<<<1, 256>>>(dA, dO, dT, 20);
     hipDeviceSynchronize();
-    hipMemcpy(hT, dT, 128, hipMemcpyDeviceToHost);
+    hipMemcpy(hT, dT, 256, hipMemcpyDeviceToHost);
     printf("F32_EXP=%d  factor32 %lld memtime ticks (~ core cycles); pivot wave done %lld, inverse waves done %lld; per panel:",
            F32_EXP, hT[2] - hT[0], hT[3] - hT[0], hT[4] - hT[0]);
     for (int q = 0; q < 8; q++) printf(" %lld", hT[5 + q] - (q ? hT[4 + q] : hT[0]));
+    printf("\n   inverse wave, per panel (saw the panel at, rows stored at; cycles since entry):");
+    for (int q = 0; q < 8; q++) printf(" %lld/%lld", hT[16 + 2 * q] - hT[0], hT[17 + 2 * q] - hT[0]);
+    printf("\n   pivot wave published at:");
+    for (int q = 0; q < 8; q++) printf(" %lld", hT[5 + q] - hT[0]);
     printf("\n");
   }
   hipMemcpy(out.data(), dO, 16 * GB * GB, hipMemcpyDeviceToHost);
