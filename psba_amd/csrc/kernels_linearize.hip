@@ -187,6 +187,169 @@ __global__ __launch_bounds__(TILE_OBS) void k_linearize(LinArgs p) {
   for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
 }
 
+// ---- round 4: the same pass with fewer LDS round trips per tile -----------------------------------------
+// k_linearize above spends a tile in five dependent phases (in-kernel stamps): parameter gathers
+// 4900-6900 cycles, Jacobian 1000, staging + camera atomics 4000-6200, first half of W 1900-3100, per-point
+// sums through a second LDS pass 4500-5000, second half of W 2100-2700.  Here
+//  * V_i and g_b,i are summed ACROSS THE LANES of a point (observations are point-major: a point's observations
+//    are adjacent lanes): a segmented Hillis-Steele scan with ds_bpermute shuffles, log2(longest track in the
+//    wave) steps of nine values -- no B / e staging, no second pass, no loop whose length is the longest track.
+//    A point that straddles two waves is finished through 40 doubles of LDS behind the tile's one barrier.
+//    (The sums are no longer taken in the reference's camera order, compute_V.cl:20-34: a fixed tree instead;
+//    parity is held to 1e-11, not bit for bit -- as it already is for U and g_a.)
+//  * the LDS that B / e needed holds the second half of W: one staging, one barrier, one flush per tile;
+//  * the NEXT tile's indices and the eighteen parameter doubles they lead to are fetched as soon as this tile's
+//    Jacobian is done, so their latency runs under the camera atomics, the scan and the W flush.
+template <bool DUMP, bool GACC>
+__global__ __launch_bounds__(TILE_OBS) void k_linearize2(LinArgs p) {
+  __shared__ double sW[TILE_OBS * 19];          // W blocks of the tile (row stride 19 doubles: odd, conflict-free stores)
+  __shared__ double sCarV[TILE_OBS / 64][9];    // a wave's last lane: its scan values (the tail of its last segment)
+  __shared__ int sCarP[TILE_OBS / 64][3];       // point of the wave's first lane, of its last lane, whole wave one point?
+  extern __shared__ double sAcc[];              // [nC][27]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.pub_dst && blockIdx.x == 0) {
+    if (tid < NSCAL) p.pub_dst[tid] = p.pub_src[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) p.pub_dst[NSCAL] = p.pub_stamp;
+  }
+  const int nAcc = GACC ? 0 : p.nC * CAM_ACC;
+  for (int t = tid; t < nAcc; t += TILE_OBS) sAcc[t] = 0.0;
+  __syncthreads();
+
+  int tile = blockIdx.x;
+  int4 dsc = tile < p.nTiles ? p.tile_desc[tile] : make_int4(0, 0, 0, 0);
+  int i = 0, j = 0;
+  double cc[9], cam[6], M[3];
+  double2 m = make_double2(0.0, 0.0);
+  // prologue: the first tile's operands
+  if (dsc.z + tid < dsc.w) {
+    i = p.iidx[dsc.z + tid];
+    j = p.jidx[dsc.z + tid];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) M[k] = p.pts[3 * (size_t)i + k];
+    m = reinterpret_cast<const double2 *>(p.impts)[dsc.z + tid];
+  }
+  for (; tile < p.nTiles; tile += gridDim.x) {
+    const int o0 = dsc.z, o1 = dsc.w;
+    const int a = o0 + tid;
+    const bool act = a < o1;
+    const int tn = tile + gridDim.x;
+    const int4 dn = tn < p.nTiles ? p.tile_desc[tn] : make_int4(0, 0, 0, 0);
+    double v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = 0.0;
+    const int pi = act ? i : -1 - tid;  // inactive lanes: ids of their own, never merged
+    const int jc = j;
+    if (act) {
+      double e[2], A[12], B[6];
+      linearize_obs(cc, cc + 5, cam, M, m.x, m.y, e, A, B);
+      if (DUMP) {
+        p.dbg_ex[2 * (size_t)a] = e[0];
+        p.dbg_ex[2 * (size_t)a + 1] = e[1];
+#pragma unroll
+        for (int k = 0; k < 12; k++) p.dbg_JA[12 * (size_t)a + k] = A[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.dbg_JB[6 * (size_t)a + k] = B[k];
+      }
+      // W_ij = coeff * A^T B, 6x3 row-major, staged (row stride 19) and flushed as contiguous runs below
+      double *w = sW + 19 * tid;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) w[3 * r + c] = p.coeff * (A[r] * B[c] + A[6 + r] * B[3 + c]);
+      // this observation's terms of V_i (upper triangle) and g_b,i
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = r; c < 3; c++) v[q++] = B[r] * B[c] + B[3 + r] * B[3 + c];
+#pragma unroll
+      for (int r = 0; r < 3; r++) v[6 + r] = B[r] * e[0] + B[3 + r] * e[1];
+      // camera sums: upper triangle of A^T A, then A^T e
+      if (p.mode != 1 && !GACC) {
+        double *acc = sAcc + CAM_ACC * (size_t)jc;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = r; c < 6; c++) atomicAdd(&acc[k++], A[r] * A[c] + A[6 + r] * A[6 + c]);
+#pragma unroll
+        for (int r = 0; r < 6; r++) atomicAdd(&acc[21 + r], A[r] * e[0] + A[6 + r] * e[1]);
+      }
+    }
+    // the next tile's operands: in flight during everything below
+    i = j = 0;
+    if (dn.z + tid < dn.w) {
+      i = p.iidx[dn.z + tid];
+      j = p.jidx[dn.z + tid];
+#pragma unroll
+      for (int k = 0; k < 9; k++) cc[k] = p.camconst[9 * j + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cam[k] = p.cams[6 * j + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) M[k] = p.pts[3 * (size_t)i + k];
+      m = reinterpret_cast<const double2 *>(p.impts)[dn.z + tid];
+    }
+    // segmented inclusive scan over the lanes of a point
+    if (p.mode != 3) {
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int pu = __shfl_up(pi, d, 64);
+        const bool ok = lane >= d && pu == pi;
+        if (!__any(ok)) break;  // no segment of this wave reaches d lanes back: none reaches 2 d either
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const double vu = __shfl_up(v[k], d, 64);
+          v[k] += ok ? vu : 0.0;
+        }
+      }
+    }
+    const int pn = __shfl_down(pi, 1, 64);  // (lane 63 gets its own value back: handled below)
+    const int p_first = __shfl(pi, 0, 64), p_last = __shfl(pi, 63, 64);
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) sCarV[wave][k] = v[k];
+      sCarP[wave][0] = p_first;
+      sCarP[wave][1] = p_last;
+      sCarP[wave][2] = p_first == p_last;
+    }
+    __syncthreads();
+    // W out: contiguous runs from the staged rows
+    if (p.mode != 2) {
+      double *dst = p.W + 18 * (size_t)o0;
+      const int n = 18 * (o1 - o0);
+      for (int t = tid; t < n; t += TILE_OBS) dst[t] = sW[19 * (t / 18) + t % 18];
+    }
+    // the last lane of a point's run stores V_i | g_b,i; a run that began in earlier waves collects their tails
+    if (act && p.mode != 3) {
+      const bool cont = lane == 63 && wave + 1 < TILE_OBS / 64 && sCarP[wave + 1][0] == pi;  // goes on in the next wave
+      const bool tail = lane == 63 ? !cont : pn != pi;
+      if (tail) {
+        if (pi == p_first) {  // this wave's first run: may have begun before lane 0
+          for (int w2 = wave - 1; w2 >= 0 && sCarP[w2][1] == pi; w2--) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) v[k] += sCarV[w2][k];
+            if (!sCarP[w2][2]) break;  // that wave held the beginning of the run
+          }
+        }
+        double *pv = p.PV + 9 * (size_t)pi;
+#pragma unroll
+        for (int k = 0; k < 9; k++) pv[k] = (k < 6 ? p.coeff : p.coeff_g) * v[k];
+      }
+    }
+    dsc = dn;
+    __syncthreads();  // sW and the carry rows are free again
+  }
+  if (GACC) return;
+  double *slab = p.campart + (size_t)blockIdx.x * nAcc;
+  for (int t = tid; t < nAcc; t += TILE_OBS) slab[t] = sAcc[t];
+}
+
 // A point seen by more than TILE_OBS cameras (no limit in the reference: compute_V.cl:6-38,
 // compute_g.cl:43-58 loop over all cameras): one workgroup walks its observations, TILE_OBS at a
 // time.  W as in k_linearize; V_i and g_b,i summed over the workgroup; the camera sums go with global
@@ -449,12 +612,15 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
     const char *m = getenv("PSBA_LIN_MODE");
     a.mode = m ? atoi(m) : 0;
   }
+  const bool v1 = getenv("PSBA_LIN_V1") != nullptr;  // round 1-3's kernel (per-point sums through a second LDS pass): cross-check
   const size_t lds = h->cam_global ? 0 : sizeof(double) * CAM_ACC * (size_t)d.nC;
   // static LDS of the kernel is ~54 KiB: beyond 64 KiB in all, the dynamic part needs the attribute
   if (!h->lin_attr_set && lds > 8 * 1024) {
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize<true, false>, attr, 100 * 1024));
     PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize<false, false>, attr, 100 * 1024));
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize2<true, false>, attr, 100 * 1024));
+    PSBA_HIP(h, hipFuncSetAttribute((const void *)k_linearize2<false, false>, attr, 100 * 1024));
     h->lin_attr_set = true;
   }
   double *Uo = ahead ? h->U_alt : h->U, *gao = ahead ? h->ga_alt : h->ga;
@@ -463,10 +629,14 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
     if (h->cam_global) {
       PSBA_HIP(h, hipMemsetAsync(h->camacc, 0, sizeof(double) * CAM_ACC * (size_t)d.nC, h->stream));
       const int grid = d.nTiles < 2048 ? d.nTiles : 2048;
-      if (dump)
+      if (v1 && dump)
         hipLaunchKernelGGL((k_linearize<true, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
-      else
+      else if (v1)
         hipLaunchKernelGGL((k_linearize<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      else if (dump)
+        hipLaunchKernelGGL((k_linearize2<true, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
+      else
+        hipLaunchKernelGGL((k_linearize2<false, true>), dim3(grid), dim3(TILE_OBS), 0, h->stream, a);
       if (h->nLong) {
         if (dump)
           hipLaunchKernelGGL((k_linearize_long<true, true>), dim3(h->nLong), dim3(TILE_OBS), 0, h->stream, a, h->long_pts, (double *)nullptr);
@@ -478,10 +648,14 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
       hipLaunchKernelGGL(k_cam_finalize, dim3((42 * d.nC + 255) / 256), dim3(256), 0, h->stream, h->camacc, d.nC,
                          h->coeff, h->coeff_g, Uo, gao);
     } else {
-      if (dump)
+      if (v1 && dump)
         hipLaunchKernelGGL((k_linearize<true, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
-      else
+      else if (v1)
         hipLaunchKernelGGL((k_linearize<false, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+      else if (dump)
+        hipLaunchKernelGGL((k_linearize2<true, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
+      else
+        hipLaunchKernelGGL((k_linearize2<false, false>), dim3(h->nPart), dim3(TILE_OBS), lds, h->stream, a);
       int nslab = h->nPart;
       if (h->nLong) {  // their camera sums: one more slab
         double *slab = h->campart + (size_t)h->nPart * d.nC * CAM_ACC;

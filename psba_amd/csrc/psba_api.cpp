@@ -352,6 +352,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   TRY(dev_alloc(h, &h->W_alt, (size_t)18 * d.nO));
   TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
   TRY(dev_alloc(h, &h->PV_alt, (size_t)9 * d.nP));
+  // (a point without observations is never written by K1, whose stores come from the last lane of a point's run
+  // of observations: its V_i and g_b,i are the zeros put here)
+  PSBA_HIP(h, hipMemsetAsync(h->PV, 0, sizeof(double) * 9 * (size_t)d.nP, h->stream));
+  PSBA_HIP(h, hipMemsetAsync(h->PV_alt, 0, sizeof(double) * 9 * (size_t)d.nP, h->stream));
   TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
   TRY(dev_alloc(h, &h->U_alt, (size_t)36 * d.nC));
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
