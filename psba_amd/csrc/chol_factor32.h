@@ -291,10 +291,17 @@ __device__ __forceinline__ void f32_inverse_mfma(Factor32Lds &s, int lane, long 
 
 // Factor the 32x32 block held in s.D (lower triangle valid) and invert the factor into s.Li.
 // The caller has zeroed s.flag[] / s.fail and synchronised; needs waves 0..3 of the workgroup.
-template <bool TIMED = false>
-__device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim = nullptr) {
+struct F32NoBackground {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// BG: what the waves beyond the fourth do meanwhile (k_cholg_tail: the block updates that are not on the way to
+// the next diagonal block); called with wave - 4, must not touch s
+template <bool TIMED = false, class BG = F32NoBackground>
+__device__ __forceinline__ void factor32(Factor32Lds &s, int tid, long long *tim = nullptr, const BG &bg = BG()) {
   const int lane = tid & 63, wave = tid >> 6;
-  if (wave == 0) {
+  if (wave >= 4) {
+    bg(wave - 4);
+  } else if (wave == 0) {
     f32_pivot_wave<TIMED>(s, lane, tim);
     if (TIMED && lane == 0) tim[3] = (long long)__builtin_amdgcn_s_memtime();
   } else if (wave == 2) {

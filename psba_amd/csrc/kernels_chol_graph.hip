@@ -205,7 +205,7 @@ __device__ __forceinline__ d4 update_tile(const double *Lw, const double *Lx, in
 }
 
 // workgroup 0's tail: factor the next diagonal block (in s.D) and store factor + inverse
-__device__ __forceinline__ void factor_next(Factor32Lds &s, double *Lx, int ld, int jn, double *linv,
+__device__ __forceinline__ void factor_next_block(Factor32Lds &s, double *Lx, int ld, int jn, double *linv,
                                             int *status, int tid) {
   factor32(s, tid);
   double *lio = linv + (size_t)(jn / GB) * GB * GB;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_cholg_update(double *Lw, double *Lx, in
       for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
     }
     __syncthreads();
-    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    factor_next_block(s, Lx, ld, j + GB, linv, status, tid);
     return;
   }
   int TR, TC;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_cols(double *Lw, double *L
       for (int r = 0; r < 4; r++) s.D[16 * (TR - T0) + lk + 4 * r][16 * (TC - T0) + li] = c[r];
     }
     __syncthreads();
-    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    factor_next_block(s, Lx, ld, j + GB, linv, status, tid);
     return;
   }
   long long idx = (long long)(blockIdx.x - 1) * 4 + wave;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide(double *Lw, double *L
       for (int r = 0; r < 4; r++) s.D[16 * (TR - Tw) + lk + 4 * r][16 * (TC - Tw) + li] = c[r];
     }
     __syncthreads();
-    factor_next(s, Lx, ld, 16 * Tw, linv, status, tid);
+    factor_next_block(s, Lx, ld, 16 * Tw, linv, status, tid);
     return;
   }
   const long long MR = (nT - 1 - Tw) / 2;  // macro rows: 32-row blocks below / right of the super-panel
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
       for (int r = 0; r < 4; r++) s.D[16 * (TR - Tw) + lk + 4 * r][16 * (TC - Tw) + li] = c[r];
     }
     __syncthreads();
-    factor_next(s, Lx, ld, 16 * Tw, linv, status, tid);
+    factor_next_block(s, Lx, ld, 16 * Tw, linv, status, tid);
     return;
   }
   // (grouping the blocks in 8x8 patches per XCD took the L2 misses from 41 % to 23 % of the requests
@@ -512,8 +512,10 @@ constexpr int XS = 34;  // row stride of the X scratch: 16-byte aligned rows, co
 // transformed identity rows; 0 in the mid-size chain, which solves backward through the factor).
 // TE >= 0: the 32-column step inside a super-panel of the two-level chain -- only the tiles of the
 // tile columns [T0, TE), all rows below (as k_cholg_update_cols, whose trsm kernel this saves).
+// factor_next = 0: the launch in front of k_cholg_tail -- workgroup 0 updates the three tiles of the next diagonal
+// block like any other tile and does not factor it (the tail kernel factors the whole trailing triangle)
 __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int ld, int j, int nT, int nId, int TE,
-                                                     double *linv, int *status) {
+                                                     double *linv, int *status, int factor_next) {
   __shared__ Factor32Lds s;
   __shared__ double sX[4][2][16][XS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -551,11 +553,16 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     if (wave < 3) {
       const Row8 a = load_row8(&sX[0][tr][li][8 * lk]), b = load_row8(&sX[0][tc][li][8 * lk]);
       c = update_mfma(c, a, b);
+      if (!factor_next) {
+        store_c_tile(Lw, ld, T0 + tr, T0 + tc, li, lk, c);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; r++) s.D[16 * tr + lk + 4 * r][16 * tc + li] = c[r];
+        for (int r = 0; r < 4; r++) s.D[16 * tr + lk + 4 * r][16 * tc + li] = c[r];
+      }
     }
+    if (!factor_next) return;  // (uniform)
     __syncthreads();
-    factor_next(s, Lx, ld, j + GB, linv, status, tid);
+    factor_next_block(s, Lx, ld, j + GB, linv, status, tid);
     return;
   }
   int TR, TC;
@@ -854,6 +861,244 @@ __global__ __launch_bounds__(256) void k_cholg_solve(const double *Lw, const dou
   }
 }
 
+#ifdef PSBA_BUILD_EXPERIMENTS
+// ---- the last blocks of the fused chain in ONE kernel (round 4; an experiment that did not pay: built, parity-green,
+// PSBA_CHOL_TAIL=n in an experiments build; venice chain 64.0 us without, 65.0 / 63.4 / 64.0 us with n = 2 / 3 / 4.
+// In-kernel stamps at n = 4, cycles: staging of S' and of the rows 5600, four factorizations 6400 / 11 000 / 6700 /
+// 6600 -- the "background" block updates share the CU's one LDS pipe with the factorization's latency-critical
+// waves and stretch it --, the panels and diagonal updates between them 3000 / 2400 / 1600 + 1100 each, the
+// backward substitution by one wave 6700: 25.6 us for what three panel launches and the solve kernel do in 24.6.
+// Concentrating work on one CU is what the panel launches avoid) -------------------------------------
+// A panel launch costs ~3.5 us besides the 32 pivots of its diagonal block (kernel boundary 1.9, first loads of
+// what other CUs wrote 1.2, stores 0.5), and towards the end of the chain it has next to nothing to do for the
+// rest of the chip.  With the factorization complete up to column jl, the solution only needs the trailing
+// Schur complement S' (columns >= jl, all earlier panels applied), the same columns r' of the e_a row and R_i of
+// the identity rows:      x_i = sum_{c < jl} z_i[c] y[c]  +  R_i S'^-1 r'
+// (k_cholg_solve is the case of one trailing block).  Here the tail is nt <= 4 blocks: every workgroup stages the
+// lower block triangle of S' (at most 10 blocks of 32x32) in LDS and factors it by itself -- factor32 per diagonal
+// block on waves 0-3, the panel below it and the next diagonal block's update by all eight waves between two
+// factorizations (MFMA from LDS), the remaining block updates by waves 4-7 in the shadow of the next
+// factorization --, solves S' w = r' block by block with the stored inverses, and then forms its eight rows of
+// x (one wave each).  All workgroups do the same factorization: nobody waits for anybody, and nt - 1 panel
+// launches and the solve kernel become one launch.
+constexpr int TAIL_MAX = 4;
+struct TailLds {
+  Factor32Lds s;
+  double B[TAIL_MAX * (TAIL_MAX + 1) / 2][GB][GB + 1];  // block (r, c), c <= r, at r (r + 1) / 2 + c: S', then its factor
+  double Li[TAIL_MAX][GB][GB + 1];                      // inverses of the diagonal blocks of the factor
+  double r[TAIL_MAX * GB], q[16][GB];                   // r' -> y' -> w; partial sums of the mat-vecs
+};
+__device__ __forceinline__ int tail_idx(int r, int c) { return r * (r + 1) / 2 + c; }
+
+// one 16x16 tile of A M^T for two 32x32 blocks in LDS: sum_k A[16 ti + i][k] M[16 tj + j][k]
+__device__ __forceinline__ d4 tail_abt(const double (*A)[GB + 1], const double (*M)[GB + 1], int ti, int tj, int li, int lk) {
+  d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 8; t += 2) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * ti + li][4 * t + lk], M[16 * tj + li][4 * t + lk], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * ti + li][4 * t + 4 + lk], M[16 * tj + li][4 * t + 4 + lk], c1, 0, 0, 0);
+  }
+  return c0 + c1;
+}
+
+// a 32x32 mat-vec by ONE wave from LDS (no barrier): out[r] = sum_k M[r][k] v[k] (TRANS: sum_k M[k][r] v[k]);
+// lane = (row, half): 16 products each, the halves added with one lane swap.  Every lane returns out[lane & 31].
+template <bool TRANS>
+__device__ __forceinline__ double tail_matvec(const double (*M)[GB + 1], const double *v, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 16; k++) a4[k & 3] += (TRANS ? M[16 * h + k][r] : M[r][16 * h + k]) * v[16 * h + k];
+  const double a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  return a + __shfl_xor(a, 32, 64);
+}
+
+// what the waves beyond the fourth do beside the factorization of diagonal block b + 1 (b = the column whose
+// panel has just been formed): waves 5 and 7 (the SIMDs of the inverse wave and of the nearly idle fourth wave --
+// a busy wave beside the pivot wave or the tile wave stretched the factorization from 6450 to 9150 cycles) take
+// the tiles of the blocks (r, c), b + 1 <= c <= r < nt, (r, c) != (b + 1, b + 1); wave 6 carries the right-hand
+// side along: y'_b = L_bb^-1 r'_b, then r'_c -= L_cb y'_b for the blocks below.
+struct TailBackground {
+  TailLds *t;
+  int b, nt, lane;
+  __device__ __forceinline__ void operator()(int w) const {
+    if (b < 0) return;
+    if (w == 2) {
+      const double yb = tail_matvec<false>(t->Li[b], t->r + GB * b, lane);
+      if (lane < GB) t->r[GB * b + lane] = yb;  // (a wave's LDS operations execute in order: the reads above are done)
+      for (int c = b + 1; c < nt; c++) {
+        const double u = tail_matvec<false>(t->B[tail_idx(c, b)], t->r + GB * b, lane);
+        if (lane < GB) t->r[GB * c + lane] -= u;
+      }
+      return;
+    }
+    if (w != 1 && w != 3) return;
+    const int me = w >> 1, li = lane & 15, lk = lane >> 4;
+    int task = 0;
+    for (int r = b + 2; r < nt; r++)
+      for (int c = b + 1; c <= r; c++)
+        for (int tt = 0; tt < 4; tt++) {
+          const int ti = tt >> 1, tj = tt & 1;
+          if (r == c && tj > ti) continue;  // upper tile of a diagonal block
+          if ((task++ & 1) != me) continue;
+          const d4 u = tail_abt(t->B[tail_idx(r, b)], t->B[tail_idx(c, b)], ti, tj, li, lk);
+          double(*dst)[GB + 1] = t->B[tail_idx(r, c)];
+#pragma unroll
+          for (int e = 0; e < 4; e++) dst[16 * ti + lk + 4 * e][16 * tj + li] -= u[e];
+        }
+  }
+};
+
+template <int NZ>
+__global__ __launch_bounds__(512) void k_cholg_tail(const double *Lw, const double *Lx, int ld, int n, int n32, int nt,
+                                                    double *x, int *status, long long *tim) {
+#define TAIL_STAMP(k) \
+  if (tim && blockIdx.x == 0 && threadIdx.x == 0) tim[k] = (long long)__builtin_amdgcn_s_memtime()
+  TAIL_STAMP(0);
+  extern __shared__ __align__(32) unsigned char tail_smem[];
+  TailLds &T = *reinterpret_cast<TailLds *>(tail_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x * 8 + wave;
+  const int li = lane & 15, lk = lane >> 4;
+  const int jl = n32 - GB * nt, nw = GB * nt;  // first column and width of the tail
+  const int rr = tid / GB, cc = tid % GB;     // element (rr, cc) and (rr + 16, cc) of a 32x32 block
+  // ---- everything this workgroup reads from memory is requested up front ----
+  double sv[TAIL_MAX * (TAIL_MAX + 1) / 2][2];  // S' (lower block triangle), two elements per thread and block
+#pragma unroll
+  for (int r = 0; r < TAIL_MAX; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) {
+      const double *src = Lw + (size_t)(jl + GB * (r < nt ? r : 0) + rr) * ld + jl + GB * (r < nt ? c : 0) + cc;
+      sv[r * (r + 1) / 2 + c][0] = src[0];
+      sv[r * (r + 1) / 2 + c][1] = src[(size_t)16 * ld];
+    }
+  const double rk = tid < nw ? Lw[(size_t)n32 * ld + jl + tid] : 0.0;
+  // this wave's row of the solution: the part left of the tail, and R_i (generated for the rows of the tail)
+  const bool row = i < n;
+  const double *y = Lx + (size_t)n32 * ld;
+  const double *z = Lx + (size_t)(n32 + 16 + (row ? i : 0)) * ld;
+  double zv[NZ], yv[NZ], rt[2];
+#pragma unroll
+  for (int m = 0; m < NZ; m++) {
+    const int c = lane + 64 * m;
+    const bool on = row && c < jl && c >= (i & ~15);  // left of the diagonal tile: zeros, never written
+    zv[m] = on ? z[c] : 0.0;
+    yv[m] = on ? y[c] : 0.0;
+  }
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const int k = lane + 64 * m;
+    rt[m] = 0.0;
+    if (row && k < nw) rt[m] = i >= jl ? (double)(k == i - jl) : Lw[(size_t)(n32 + 16 + i) * ld + jl + k];
+  }
+#pragma unroll
+  for (int r = 0; r < TAIL_MAX; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++)
+      if (r < nt) {
+        double(*dst)[GB + 1] = (r == 0 && c == 0) ? T.s.D : T.B[r * (r + 1) / 2 + c];  // the first diagonal block: where it is factored
+        dst[rr][cc] = sv[r * (r + 1) / 2 + c][0];
+        dst[rr + 16][cc] = sv[r * (r + 1) / 2 + c][1];
+      }
+  if (tid < nw) T.r[tid] = rk;
+  if (tid == 0) T.s.fail = 0;
+  if (tid < 4) T.s.flag[tid] = 0;
+  __syncthreads();
+  TAIL_STAMP(1);
+  // ---- the factorization of S', block column by block column (the diagonal block of the turn is in T.s.D) ----
+  for (int b = 0; b < nt; b++) {
+    const TailBackground bg = {&T, b - 1, nt, lane};
+    TAIL_STAMP(2 + 4 * b);
+    factor32<false, TailBackground>(T.s, tid, nullptr, bg);  // (ends with a barrier: the background work is in)
+    TAIL_STAMP(3 + 4 * b);
+    // L_bb^-1 for the solve and for wave 6; the panel below, L_rb = A_rb L_bb^-T, held in registers until
+    // everybody has read its operands (it is formed in place)
+    T.Li[b][rr][cc] = f32_Linv(T.s, rr, cc);
+    T.Li[b][rr + 16][cc] = f32_Linv(T.s, rr + 16, cc);
+    const int ntask = 4 * (nt - 1 - b);
+    d4 res[2];
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      const int task = wave + 8 * round;
+      if (task < ntask) {
+        // (the inverse straight from what factor32 left: Z scaled by 1 / sqrt(d) of its row)
+        const double(*A)[GB + 1] = T.B[tail_idx(b + 1 + task / 4, b)];
+        const int ti = (task >> 1) & 1, tj = task & 1;
+        const double sc = T.s.rsq[16 * tj + li];
+        d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * ti + li][4 * t + lk], T.s.Li[16 * tj + li][4 * t + lk] * sc, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * ti + li][4 * t + 4 + lk], T.s.Li[16 * tj + li][4 * t + 4 + lk] * sc, c1, 0, 0, 0);
+        }
+        res[round] = c0 + c1;
+      }
+    }
+    if (b + 1 == nt) break;
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      const int task = wave + 8 * round;
+      if (task < ntask) {
+        double(*dst)[GB + 1] = T.B[tail_idx(b + 1 + task / 4, b)];
+        const int ti = (task >> 1) & 1, tj = task & 1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) dst[16 * ti + lk + 4 * e][16 * tj + li] = res[round][e];
+      }
+    }
+    if (tid < 4) T.s.flag[tid] = 0;
+    __syncthreads();
+    TAIL_STAMP(4 + 4 * b);
+    // the next diagonal block, now, straight into the factorization's buffer: A - L L^T (three tiles); every
+    // other update runs beside its factorization
+    if (wave < 3) {
+      const int ti = wave > 0, tj = wave > 1;
+      const d4 u = tail_abt(T.B[tail_idx(b + 1, b)], T.B[tail_idx(b + 1, b)], ti, tj, li, lk);
+      const double(*src)[GB + 1] = T.B[tail_idx(b + 1, b + 1)];
+#pragma unroll
+      for (int e = 0; e < 4; e++) T.s.D[16 * ti + lk + 4 * e][16 * tj + li] = src[16 * ti + lk + 4 * e][16 * tj + li] - u[e];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0 && blockIdx.x == 0 && T.s.fail) status[1] = status[3];
+  TAIL_STAMP(18);
+  // ---- S' w = r'.  Forward: wave 6 has carried r' along (y'_b for b < nt - 1 is in place, r'_{nt-1} has every
+  // update); the last block and the whole backward substitution by wave 0 alone -- wave-synchronous 32x32
+  // mat-vecs from LDS, no barrier (eight rounds of two barriers of 512 threads took 12 000 cycles) ----
+  if (wave == 0) {
+    const int bl = nt - 1;
+    const double yl = tail_matvec<false>(T.Li[bl], T.r + GB * bl, lane);
+    if (lane < GB) T.r[GB * bl + lane] = yl;
+    for (int b = nt - 1; b >= 0; b--) {
+      // w_b = L_bb^-T (y'_b - sum_{c > b} L_cb^T w_c)
+      double u = T.r[GB * b + (lane & 31)];
+      for (int c = b + 1; c < nt; c++) u -= tail_matvec<true>(T.B[tail_idx(c, b)], T.r + GB * c, lane);
+      if (lane < GB) T.r[GB * b + lane] = u;
+      const double wv = tail_matvec<true>(T.Li[b], T.r + GB * b, lane);
+      if (lane < GB) T.r[GB * b + lane] = wv;
+    }
+  }
+  __syncthreads();
+  TAIL_STAMP(19);
+  if (!row) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+    if (lane + 64 * m < nw) acc += rt[m] * T.r[lane + 64 * m];
+#pragma unroll
+  for (int m = 0; m < NZ; m++) acc += zv[m] * yv[m];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    x[i] = acc;
+    if (!isfinite(acc)) status[1] = status[3];
+  }
+  TAIL_STAMP(20);
+#undef TAIL_STAMP
+}
+
+#endif  // PSBA_BUILD_EXPERIMENTS
+
 // the shape of the chain for a matrix size (see enqueue_chain for the measurements behind the limits)
 struct ChainShape {
   bool fused, blocked, fused2;
@@ -901,7 +1146,7 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
       // per tile instead of 8, which pays while the step has few tiles -- per LM iteration
       // n = 3600: 2.17 against 2.36 ms, 6000: 4.72 / 4.78, 12 000 (all steps): 19.0 / 17.9)
       hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nT, 0,
-                         TE, linv, h->status);
+                         TE, linv, h->status, 1);
       continue;
     }
     hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
@@ -975,13 +1220,21 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   // redundant work is no longer free: two kernels per panel and a sequential backward solve
   const ChainShape c = chain_shape(h);
   const bool fused = c.fused, blocked = c.blocked, fused2 = c.fused2;
-  if (!skip_diag)  // else the S-reduce kernel has factored the first diagonal block already
+  // (experiments build, PSBA_CHOL_TAIL=1..4: the last `tail` blocks of the fused chain factored and solved by
+  // k_cholg_tail instead of by panel launches + k_cholg_solve; measured, no gain -- see k_cholg_tail)
+  int tail = 0;
+#ifdef PSBA_BUILD_EXPERIMENTS
+  if (const char *e = getenv("PSBA_CHOL_TAIL")) tail = fused && atoi(e) >= 0 && atoi(e) <= TAIL_MAX && atoi(e) <= n32 / GB ? atoi(e) : 0;
+#endif
+  const int jl = n32 - GB * tail;  // the panel launches stop here
+  if (!skip_diag && !(tail > 0 && jl == 0))  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
   for (int J = 0; blocked && J < n32; J += c.NB) enqueue_superpanel(h, s, c, J, 0, 0);
   for (int j = 0; !blocked && j < n32; j += GB) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;
     const long long M = (nT - 1) - T0;
+    if (tail > 0 && j >= jl) break;  // the rest is k_cholg_tail's
     if (last && fused) break;  // the last panel's trsm is part of k_cholg_solve
     if (last || !(fused || fused2)) {
       // 16-row tiles below the panel incl. the e_a tile
@@ -994,9 +1247,27 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     } else {
       const int nId = fused ? T0 : 0;
       const int grid = 1 + (int)((M * (M + 1) / 2 + M + (long long)nId * M - 3 + 3) / 4);
-      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, nId, -1, linv, h->status);
+      hipLaunchKernelGGL(k_cholg_panel, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, j, nT, nId, -1, linv, h->status,
+                         tail > 0 && j + GB >= jl ? 0 : 1);
     }
   }
+#ifdef PSBA_BUILD_EXPERIMENTS
+  if (fused && tail > 0) {
+    const size_t lds = sizeof(TailLds);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)k_cholg_tail<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void *)k_cholg_tail<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (n32 <= 640)
+      hipLaunchKernelGGL(k_cholg_tail<10>, dim3((h->d.nA + 7) / 8), dim3(512), lds, s, Lw, Lx, ld, h->d.nA, n32, tail, h->dp,
+                         h->status, h->chol_tim);
+    else
+      hipLaunchKernelGGL(k_cholg_tail<16>, dim3((h->d.nA + 7) / 8), dim3(512), lds, s, Lw, Lx, ld, h->d.nA, n32, tail, h->dp,
+                         h->status, h->chol_tim);
+  } else
+#endif
   if (fused) {
     if (n32 <= 640)
       hipLaunchKernelGGL(k_cholg_solve<10>, dim3((h->d.nA + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, h->d.nA, n32, h->dp,

@@ -781,11 +781,11 @@ int psba_schur_solve(psba_handle h) {
   }
   TRY(launch_chol_solve(h));
   if (h->chol_tim) {
-    long long t[16];
+    long long t[32];
     PSBA_HIP(h, hipMemcpyAsync(t, h->chol_tim, sizeof t, hipMemcpyDeviceToHost, h->stream));
     PSBA_HIP(h, hipStreamSynchronize(h->stream));
-    fprintf(stderr, "chol diag-kernel stamps (cycles since entry):");
-    for (int k = 1; k < 16; k++) fprintf(stderr, " %lld", t[k] - t[0]);
+    fprintf(stderr, "chol stamps (cycles since the first):");
+    for (int k = 1; k < 32; k++) fprintf(stderr, " %lld", t[k] ? t[k] - t[0] : 0);
     fprintf(stderr, "\n");
   }
   h->assembled = false;  // S is overwritten by its factor

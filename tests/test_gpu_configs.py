@@ -1005,3 +1005,33 @@ def test_packed_sums_line_up_between_ranks(name, nr, problems, monkeypatch):
     close(flat, newp, 1e-9, "proposal over the shards")
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("tail", [1, 2, 3, 4])
+def test_tail_kernel_experiment(tail, monkeypatch):
+    """Round 4's k_cholg_tail (the last blocks of the fused chain factored and solved by one kernel; measured, no
+    gain, experiments build only: PSBA_BUILD_EXPERIMENTS=1 python psba_amd/build.py, PSBA_LIB=.../libpsba_hip_exp.so):
+    dpa and the try's scalars against the panel chain, on 52 / 20 / 5 cameras (n32 = 320, 128, 32)."""
+    import psba_amd
+    from psba_amd import capi
+    import psba_amd.synth as synth
+    if not capi.HAS_EXPERIMENTS:
+        pytest.skip("experiment build only (PSBA_BUILD_EXPERIMENTS=1)")
+    for n_cams in (52, 20, 5):
+        if tail > 6 * n_cams // 32 + (6 * n_cams % 32 > 0):
+            continue
+        prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=4.0, seed=5 + n_cams)
+        outs = []
+        for t in (0, tail):
+            monkeypatch.setenv("PSBA_CHOL_TAIL", str(t))
+            h = psba_amd.Psba(0)
+            h.upload_problem(prob)
+            h.linearize(1.0, 1.0)
+            mu = 1e-3 * h.max_diag()
+            h.schur_assemble(mu); h.schur_reduce(); h.schur_solve()
+            sc = h.backsub(mu)
+            assert sc.status == 0
+            outs.append((h.get_dp()[: 6 * n_cams].copy(), sc.new_cost))
+            h.close()
+        assert np.abs(outs[1][0] - outs[0][0]).max() <= 1e-10 * np.abs(outs[0][0]).max()
+        assert abs(outs[1][1] - outs[0][1]) <= 1e-12 * outs[0][1]
