@@ -377,6 +377,11 @@ int psba_set_sparse_pattern(psba_handle h, const unsigned char *flags, long long
  *   psba_chol_dist_block(B, set, buf, &n)  get (set = 0) / set the packed block B; n = its doubles
  *   psba_chol_dist_finish    the backward solve: dpa, as after psba_schur_solve */
 int psba_chol_dist_shape(psba_handle h, int *n32, int *NB, int *sharded);
+/* host only: the column exchange in front of the super-panel at column JE, as the RCCL path performs it --
+ * out4[k] = {block B, owner rank (B mod nranks), slot of the exchange buffer, doubles}; returns the number of
+ * blocks (0: none, the last super-panel), < 0 if cap is too small.  The owner of block B packs rows 64 B .. n32
+ * (the e_a row) of its min(64, n32 - 64 B) columns, everybody else unpacks them. */
+int psba_chol_dist_exchange_plan(int n32, int NB, int nranks, int JE, long long *out4, int cap);
 int psba_chol_dist_begin(psba_handle h);
 int psba_chol_dist_superpanel(psba_handle h, int J);
 int psba_chol_dist_block(psba_handle h, int B, int set, double *buf, long long *n_doubles);

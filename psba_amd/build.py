@@ -11,9 +11,9 @@ SOURCES = ["psba_api.cpp", "schur_plan.cpp", "lm_loop.cpp", "tr_loop.cpp", "sba_
 # PSBA_BUILD_EXPERIMENTS=1: also the rejected experiments (round 3's K2 ring route) and their test hooks
 EXPERIMENTS = bool(os.environ.get("PSBA_BUILD_EXPERIMENTS"))
 if EXPERIMENTS:
-    SOURCES += ["kernels_schur_ring.hip", "schur_ring_plan.cpp"]
+    SOURCES += ["kernels_schur_ring.hip", "schur_ring_plan.cpp", "kernels_schur_modes.hip"]
 OUT = os.path.join(HERE, "libpsba_hip_exp.so" if EXPERIMENTS else "libpsba_hip.so")
-HEADERS = ["psba_internal.h", "camera_model.h", "chol_factor32.h", "schur_common.h", os.path.join("..", "..", "include", "psba_hip.h")]
+HEADERS = ["psba_internal.h", "camera_model.h", "chol_factor32.h", "schur_common.h", "schur_lds_args.h", os.path.join("..", "..", "include", "psba_hip.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-result", "-x", "hip"] + (["-DPSBA_BUILD_EXPERIMENTS"] if EXPERIMENTS else [])

@@ -140,6 +140,7 @@ SIGNATURES = [
     ("psba_set_sparse_S", C.c_int, [_h, _dp, _dp]),
     ("psba_sparse_pattern", C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
     ("psba_set_sparse_pattern", C.c_int, [_h, C.POINTER(C.c_ubyte), C.c_longlong]),
+    ("psba_chol_dist_exchange_plan", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
     ("psba_chol_dist_shape", C.c_int, [_h, _ip, _ip, _ip]),
     ("psba_chol_dist_begin", C.c_int, [_h]),
     ("psba_chol_dist_superpanel", C.c_int, [_h, C.c_int]),
@@ -297,6 +298,15 @@ def owner_plan(n_cams, n_pts, iidx, jidx, pattern=None):
     finally:
         lib.psba_owner_plan_destroy(p)
     return dict(waves=waves, units=units, prod=prod.reshape(rows, 64, 2), blocks=blocks, diag_slot=diag, products=products)
+
+
+def chol_dist_exchange_plan(n32, NB, nranks, JE):
+    """[(block, owner, slot, doubles)] of the column exchange in front of the super-panel at column JE."""
+    out = np.zeros((64, 4), dtype=np.int64)
+    n = lib.psba_chol_dist_exchange_plan(int(n32), int(NB), int(nranks), int(JE), out.ctypes.data_as(C.POINTER(C.c_longlong)), 64)
+    if n < 0:
+        raise PsbaError(n, "psba_chol_dist_exchange_plan failed")
+    return [tuple(int(v) for v in row) for row in out[:n]]
 
 
 def ring_plan(n_cams, n_pts, iidx, jidx):

@@ -1333,11 +1333,31 @@ int chol_dist_finish(psba_ctx *h) {
   return PSBA_OK;
 }
 
+// the column exchange in front of the super-panel that begins at column JE: which 64-column blocks travel, who
+// owns each (the rank that updated it: B mod nranks), the slot of the exchange buffer it is packed into and its
+// length in doubles (rows from the block's own diagonal to the e_a row, by min(64, n32 - 64 B) columns -- the last
+// block is half a block when n32 mod 64 = 32).  One function for the RCCL path below and for the host test that
+// replays it for 2, 3 and 8 ranks (tests/test_host.py): out[k] = {B, owner, slot, doubles}; returns the count.
+int chol_dist_exchange_plan(int n32, int NB, int nranks, int JE, long long (*out)[4], int cap) {
+  if (JE >= n32 || NB <= 0 || nranks <= 0) return 0;
+  const int B0 = JE / 64, B1 = ((JE + NB < n32 ? JE + NB : n32) + 63) / 64;
+  int k = 0;
+  for (int B = B0; B < B1; B++, k++) {
+    if (k >= cap) return -1;
+    const long long cols = n32 - 64 * B < 64 ? n32 - 64 * B : 64;
+    out[k][0] = B;
+    out[k][1] = B % nranks;
+    out[k][2] = B - B0;
+    out[k][3] = (long long)(n32 + 1 - 64 * B) * cols;
+  }
+  return k;
+}
+
 static int chol_dist_comm(psba_ctx *h) {
   const ChainShape c = chain_shape(h);
   const int n32 = h->n32;
+  const size_t per = (size_t)(n32 + 1) * 64;  // a slot of the exchange buffer
   if (!h->dist_buf) {
-    const size_t per = (size_t)(n32 + 1) * 64;
     if (hipMalloc((void **)&h->dist_buf, sizeof(double) * per * (size_t)(c.NB / 64 + 1)) != hipSuccess)
       return fail(h, PSBA_E_HIP, "no memory for the column exchange buffers");
   }
@@ -1346,21 +1366,21 @@ static int chol_dist_comm(psba_ctx *h) {
     rc = chol_dist_superpanel(h, J);
     const int JE = J + c.NB;
     if (JE >= n32 || rc != PSBA_OK) break;
-    const int B0 = JE / 64, B1 = ((JE + c.NB < n32 ? JE + c.NB : n32) + 63) / 64;  // (n32 % 64 == 32: the last block is half a block)
-    const size_t per = (size_t)(n32 + 1) * 64;
-    for (int B = B0; B < B1; B++)
-      if (B % h->nranks == h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 0);
+    long long plan[64][4];
+    const int nb = chol_dist_exchange_plan(n32, c.NB, h->nranks, JE, plan, 64);
+    if (nb < 0 || nb > c.NB / 64 + 1) return fail(h, PSBA_E_INVALID, "column exchange: %d blocks for a super-panel of %d columns", nb, c.NB);
+    for (int k = 0; k < nb && rc == PSBA_OK; k++)
+      if (plan[k][1] == h->rank) rc = chol_dist_block(h, (int)plan[k][0], h->dist_buf + (size_t)plan[k][2] * per, 0);
     if (ncclGroupStart() != ncclSuccess) return fail(h, PSBA_E_RCCL, "ncclGroupStart failed");
     bool sent = true;
-    for (int B = B0; B < B1 && sent; B++) {
-      double *b = h->dist_buf + (size_t)(B - B0) * per;
-      const size_t n = (size_t)(n32 + 1 - 64 * B) * (size_t)(n32 - 64 * B < 64 ? n32 - 64 * B : 64);
-      sent = ncclBroadcast(b, b, n, ncclDouble, B % h->nranks, h->comm, h->stream) == ncclSuccess;
+    for (int k = 0; k < nb && sent; k++) {
+      double *b = h->dist_buf + (size_t)plan[k][2] * per;
+      sent = ncclBroadcast(b, b, (size_t)plan[k][3], ncclDouble, (int)plan[k][1], h->comm, h->stream) == ncclSuccess;
     }
     if (ncclGroupEnd() != ncclSuccess || !sent)  // (the group is closed before any error return)
       return fail(h, PSBA_E_RCCL, "ncclBroadcast failed in the column exchange");
-    for (int B = B0; B < B1 && rc == PSBA_OK; B++)
-      if (B % h->nranks != h->rank) rc = chol_dist_block(h, B, h->dist_buf + (size_t)(B - B0) * per, 1);
+    for (int k = 0; k < nb && rc == PSBA_OK; k++)
+      if (plan[k][1] != h->rank) rc = chol_dist_block(h, (int)plan[k][0], h->dist_buf + (size_t)plan[k][2] * per, 1);
   }
   if (rc == PSBA_OK) rc = chol_dist_finish(h);
   return rc;

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "schur_common.h"
+#include "schur_lds_args.h"
 
 namespace psba {
 
@@ -190,35 +191,11 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_long(SchurArgs p, const int 
 //    k_schur_reduce sums the slabs of a group in a fixed order;
 //  * workgroups that work on the same stretch of points (for different groups of blocks)
 //    are mapped to the same XCD (blockIdx % 8) so that the re-reads of W are L2 hits.
-constexpr int SCHUR_THREADS = 1024;
-constexpr int BLK_STRIDE = 37;
-
-struct SchurLdsArgs {
-  const double *W, *PV;
-  const SchurWg *wg;
-  const unsigned long long *items;
-  double *slab;
-  int *status;
-  double *dbg_Y, *dbg_Vinv;
-  double mu;
-  int nWg, try_id;
-  // single rank: while flushing, a workgroup also adds its copies of the blocks (j, k), j <= 5
-  // (the first 32x32 diagonal block of S) into diag0 with global atomics, so that the S-reduce
-  // kernel can factor that block without gathering it from all the slabs
-  double *diag0;           // nullptr: off
-  int diag_grp[21], diag_pos[21];
-};
+// (SCHUR_THREADS, BLK_STRIDE and SchurLdsArgs: schur_lds_args.h)
 
 
-// MODE is development instrumentation (ablation timing, PSBA_SCHUR_MODE): 0 = full kernel;
-// 1 = products without the LDS atomics; 2 = no product loop; 3 = no W_b loads (wrong
-// results); 4 = zero + flush only; 5 = every row of 16 lanes on 16 distinct bank pairs by
-// construction (wrong results: what the bank conflicts of the real schedule cost); 6 = the 36
-// atomics without the 108 fp64 operations that form the values; 7 = ds_add_u64 on the values' bit
-// patterns; 8 = 6 with ds_add_u64; 9 = all loads and arithmetic, no LDS atomics; 10 / 11 = all loads,
-// V*^-1 only, 36 f64 / u64 atomics of loaded values; 12 / 13 = no record loads, arithmetic + f64 / u64
-// atomics; 14 = one a-side and two partners per turn (all of 7..14 give wrong sums).
-template <bool DUMP, int MODE>
+// one item = one product Y_a W_b^T of one point; see the schedule above
+template <bool DUMP>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   extern __shared__ double sPart[];  // [nblk][37]
   const int tid = threadIdx.x;
@@ -228,65 +205,37 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   for (int t = tid; t < BLK_STRIDE * wg.nblk; t += SCHUR_THREADS) sPart[t] = 0.0;
   __syncthreads();
 
-  const long long s1 = (MODE == 4) ? wg.item0 : wg.item1;
-  double keep = 0.0;
+  const long long s1 = wg.item1;
   // the next item word is fetched a turn ahead: its latency would otherwise sit in front of the
   // record loads of every turn (a wave has only about six turns)
   unsigned long long item_next = (wg.item0 + tid < s1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
-  constexpr int STEP = (MODE == 14 ? 2 : 1) * SCHUR_THREADS;
-  for (long long t = wg.item0 + tid; t < s1; t += STEP) {
+  for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
     const unsigned long long item = item_next;
-    if (t + STEP < s1) item_next = p.items[t + STEP];
-    // MODE 14 (timing only, wrong sums): what an item with one a-side and two partners would cost --
-    // the turn's second product takes its partner and its block from the item 1024 further on and
-    // reuses this item's W_a, V*^-1, Y, e
-    unsigned long long item2 = SCHUR_NULL_ITEM;
-    if (MODE == 14 && t + SCHUR_THREADS < s1) item2 = p.items[t + SCHUR_THREADS];
+    if (t + SCHUR_THREADS < s1) item_next = p.items[t + SCHUR_THREADS];
     if (item == SCHUR_NULL_ITEM) continue;
     const int a = wg.obs0 + (int)(item & ((1u << ITEM_OBS_BITS) - 1));
     const int i = wg.pt0 + (int)((item >> ITEM_OBS_BITS) & ((1u << ITEM_PT_BITS) - 1));
     const int boff = (int)((item >> (ITEM_OBS_BITS + ITEM_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
-    int pos = (int)(item >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
-    if (MODE == 5) pos = (tid & 15) + 16 * ((pos >> 4) % (wg.nblk >> 4));
+    const int pos = (int)(item >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
     // every address is known now: issue all loads of the product together
     const double *pv = p.PV + 9 * (size_t)i;
     const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
     const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
     double v[6], vi[6], w[18], wb[18];
-    double g0, g1, g2;
-    if (MODE == 12 || MODE == 13) {
-      // no record loads at all: operands made up from the item word (arithmetic and atomics only)
-      const double base = 1.0 + 1e-3 * (double)(item & 1023);
-#pragma unroll
-      for (int k = 0; k < 6; k++) v[k] = (k == 0 || k == 3 || k == 5) ? 4.0 + base : 0.25 * base;
-      g0 = base; g1 = base + 1.0; g2 = base + 2.0;
-#pragma unroll
-      for (int k = 0; k < 18; k++) {
-        w[k] = base + k;
-        wb[k] = base - k;
-      }
-    } else {
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = pv[k];
-    g0 = pv[6], g1 = pv[7], g2 = pv[8];
+    const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
       const double2 q = wa[k];
       w[2 * k] = q.x;
       w[2 * k + 1] = q.y;
     }
-    }
-    if (MODE == 12 || MODE == 13) {
-    } else if (MODE == 3) {  // products without the W_b loads
 #pragma unroll
-      for (int k = 0; k < 18; k++) wb[k] = w[k] + 1.0;
-    } else if (MODE != 2) {
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const double2 q = wb2[k];
-        wb[2 * k] = q.x;
-        wb[2 * k + 1] = q.y;
-      }
+    for (int k = 0; k < 9; k++) {
+      const double2 q = wb2[k];
+      wb[2 * k] = q.x;
+      wb[2 * k + 1] = q.y;
     }
     v[0] += p.mu;
     v[3] += p.mu;
@@ -316,35 +265,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
 #pragma unroll
       for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = -Y[k];
     }
-    if (MODE == 2) {
-      keep += Y[0] + Y[17] + e[0] + e[5];
-      continue;
-    }
     double *blk = sPart + BLK_STRIDE * pos;
-    if (MODE == 6) {
-#pragma unroll
-      for (int rc = 0; rc < 36; rc++) atomicAdd(&blk[rc], wb[rc % 18]);
-      continue;
-    }
-    if (MODE == 10 || MODE == 11) {
-#pragma unroll
-      for (int k = 0; k < 18; k++) asm volatile("" ::"v"(w[k]));
-      asm volatile("" ::"v"(g0), "v"(g1), "v"(g2));
-#pragma unroll
-      for (int rc = 0; rc < 36; rc++) {
-        if (MODE == 10)
-          atomicAdd(&blk[rc], wb[rc % 18]);
-        else
-          atomicAdd(reinterpret_cast<unsigned long long *>(&blk[rc]), (unsigned long long)__double_as_longlong(wb[rc % 18]));
-      }
-      continue;
-    }
-    if (MODE == 8) {
-#pragma unroll
-      for (int rc = 0; rc < 36; rc++)
-        atomicAdd(reinterpret_cast<unsigned long long *>(&blk[rc]), (unsigned long long)__double_as_longlong(wb[rc % 18]));
-      continue;
-    }
     // a row of the block at a time: its six values are independent chains of three operations,
     // formed side by side (one after the other, every operation would wait for the one before)
 #pragma unroll
@@ -363,51 +284,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
         if (r == 1 && c == 2) val[c] = self ? e[5] : val[c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        if (MODE == 1)
-          keep += val[c];
-        else if (MODE == 9)
-          asm volatile("" ::"v"(val[c]));
-        else if (MODE == 7 || MODE == 13)
-          atomicAdd(reinterpret_cast<unsigned long long *>(&blk[6 * r + c]), (unsigned long long)__double_as_longlong(val[c]));
-        else
-          atomicAdd(&blk[6 * r + c], val[c]);
-      }
-    }
-    if (MODE == 14 && item2 != SCHUR_NULL_ITEM) {
-      const int boffB = (int)((item2 >> (ITEM_OBS_BITS + ITEM_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
-      const int posB = (int)(item2 >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
-      const int bB = a - boffB > wg.obs0 ? a - boffB : wg.obs0;
-      const double2 *wq = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)bB);
-      double wc[18];
-#pragma unroll
-      for (int k = 0; k < 9; k++) {
-        const double2 q = wq[k];
-        wc[2 * k] = q.x;
-        wc[2 * k + 1] = q.y;
-      }
-      double *blkB = sPart + BLK_STRIDE * posB;
-      const bool selfB = boffB == 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        double val[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) val[c] = Y[3 * r] * wc[3 * c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 1], wc[3 * c + 1], val[c]);
-#pragma unroll
-        for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 2], wc[3 * c + 2], val[c]);
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          if (r == 0 && c >= 1) val[c] = selfB ? e[c - 1] : val[c];
-          if (r == 1 && c == 2) val[c] = selfB ? e[5] : val[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) atomicAdd(&blkB[6 * r + c], val[c]);
-      }
+      for (int c = 0; c < 6; c++) atomicAdd(&blk[6 * r + c], val[c]);
     }
   }
-  if (MODE != 0 && keep == 12345.678) sPart[0] = keep;
   __syncthreads();
   // two doubles per thread and step: 36 is even, so a pair never straddles a block, and the
   // slab offsets are multiples of 36 * 16 doubles: 16-byte stores
@@ -770,38 +649,16 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
       const char *m = getenv("PSBA_SCHUR_MODE");
       const int mode = m ? atoi(m) : 0;
       const dim3 G(h->nWg), B(SCHUR_THREADS);
-      if (dump)
-        hipLaunchKernelGGL((k_schur_lds<true, 0>), G, B, lds, h->stream, a);
-      else if (mode == 1)
-        hipLaunchKernelGGL((k_schur_lds<false, 1>), G, B, lds, h->stream, a);
-      else if (mode == 2)
-        hipLaunchKernelGGL((k_schur_lds<false, 2>), G, B, lds, h->stream, a);
-      else if (mode == 3)
-        hipLaunchKernelGGL((k_schur_lds<false, 3>), G, B, lds, h->stream, a);
-      else if (mode == 4)
-        hipLaunchKernelGGL((k_schur_lds<false, 4>), G, B, lds, h->stream, a);
-      else if (mode == 5)
-        hipLaunchKernelGGL((k_schur_lds<false, 5>), G, B, lds, h->stream, a);
-      else if (mode == 6)
-        hipLaunchKernelGGL((k_schur_lds<false, 6>), G, B, lds, h->stream, a);
-      else if (mode == 7)
-        hipLaunchKernelGGL((k_schur_lds<false, 7>), G, B, lds, h->stream, a);
-      else if (mode == 8)
-        hipLaunchKernelGGL((k_schur_lds<false, 8>), G, B, lds, h->stream, a);
-      else if (mode == 9)
-        hipLaunchKernelGGL((k_schur_lds<false, 9>), G, B, lds, h->stream, a);
-      else if (mode == 10)
-        hipLaunchKernelGGL((k_schur_lds<false, 10>), G, B, lds, h->stream, a);
-      else if (mode == 11)
-        hipLaunchKernelGGL((k_schur_lds<false, 11>), G, B, lds, h->stream, a);
-      else if (mode == 12)
-        hipLaunchKernelGGL((k_schur_lds<false, 12>), G, B, lds, h->stream, a);
-      else if (mode == 13)
-        hipLaunchKernelGGL((k_schur_lds<false, 13>), G, B, lds, h->stream, a);
-      else if (mode == 14)
-        hipLaunchKernelGGL((k_schur_lds<false, 14>), G, B, lds, h->stream, a);
+      bool launched = false;
+#ifdef PSBA_BUILD_EXPERIMENTS
+      if (!dump && mode > 0) launched = launch_schur_lds_mode(mode, G, B, lds, h->stream, a);  // kernels_schur_modes.hip
+#endif
+      (void)mode;
+      if (launched) {
+      } else if (dump)
+        hipLaunchKernelGGL((k_schur_lds<true>), G, B, lds, h->stream, a);
       else
-        hipLaunchKernelGGL((k_schur_lds<false, 0>), G, B, lds, h->stream, a);
+        hipLaunchKernelGGL((k_schur_lds<false>), G, B, lds, h->stream, a);
     }
     PSBA_HIP(h, hipGetLastError());
     {
@@ -865,14 +722,8 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
     if (!h->lds_attr_set) {
       const int dyn = 163840 - 256;  // allow the full 160 KiB of LDS for the partition
       const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<true, 0>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 0>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 1>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 2>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 3>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 4>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 5>, attr, dyn));
-      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false, 6>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<true>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false>, attr, dyn));
       h->lds_attr_set = true;
     }
     return launch_schur_lds(h, mu, dump);

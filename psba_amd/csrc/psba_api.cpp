@@ -941,6 +941,10 @@ int psba_chol_dist_shape(psba_handle h, int *n32, int *NB, int *sharded) {
   if (sharded) *sharded = bl;
   return PSBA_OK;
 }
+int psba_chol_dist_exchange_plan(int n32, int NB, int nranks, int JE, long long *out4, int cap) {
+  if (!out4 || cap <= 0) return PSBA_E_INVALID;
+  return psba::chol_dist_exchange_plan(n32, NB, nranks, JE, reinterpret_cast<long long(*)[4]>(out4), cap);
+}
 int psba_chol_dist_begin(psba_handle h) {
   CHECK_H(h);
   NEED(h, h->assembled, "psba_schur_assemble (and the reduction over ranks) first");
@@ -1052,7 +1056,9 @@ int psba_sparse_pattern(int nCams, int n3Dpts, int n2Dprojs, const int *iidx, co
   std::vector<int> ptr((size_t)n3Dpts + 1, 0);
   for (int a = 0; a < n2Dprojs; a++) {
     if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return PSBA_E_INVALID;
-    if (a && iidx[a] < iidx[a - 1]) return PSBA_E_INVALID;  // point-major, as psba_upload_problem requires
+    // point-major with cameras ascending inside a point, as psba_upload_problem requires (sparse_pattern's
+    // b <= a loop relies on it: unordered cameras would flag the wrong blocks silently)
+    if (a && (iidx[a] < iidx[a - 1] || (iidx[a] == iidx[a - 1] && jidx[a] <= jidx[a - 1]))) return PSBA_E_INVALID;
     ptr[(size_t)iidx[a] + 1]++;
   }
   for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[(size_t)i];
@@ -1552,7 +1558,8 @@ psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, co
   std::vector<int> ptr((size_t)n3Dpts + 1, 0);
   for (int a = 0; a < n2Dprojs; a++) {
     if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return nullptr;
-    if (a && iidx[a] < iidx[a - 1]) return nullptr;  // point-major, as psba_upload_problem requires
+    // point-major, cameras ascending inside a point, as psba_upload_problem requires
+    if (a && (iidx[a] < iidx[a - 1] || (iidx[a] == iidx[a - 1] && jidx[a] <= jidx[a - 1]))) return nullptr;
     ptr[(size_t)iidx[a] + 1]++;
   }
   for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[i];
@@ -1607,7 +1614,8 @@ psba_owner_plan_t psba_owner_plan_create(int nCams, int n3Dpts, int n2Dprojs, co
   std::vector<int> ptr((size_t)n3Dpts + 1, 0);
   for (int a = 0; a < n2Dprojs; a++) {
     if (iidx[a] < 0 || iidx[a] >= n3Dpts || jidx[a] < 0 || jidx[a] >= nCams) return nullptr;
-    if (a && iidx[a] < iidx[a - 1]) return nullptr;  // point-major, as psba_upload_problem requires
+    // point-major, cameras ascending inside a point, as psba_upload_problem requires
+    if (a && (iidx[a] < iidx[a - 1] || (iidx[a] == iidx[a - 1] && jidx[a] <= jidx[a - 1]))) return nullptr;
     ptr[(size_t)iidx[a] + 1]++;
   }
   for (int i = 0; i < n3Dpts; i++) ptr[(size_t)i + 1] += ptr[i];

@@ -335,6 +335,8 @@ int sparse_pattern(int nCams, int nObs, const int *iidx, const int *jidx, const 
 int build_ring_plan(int nCams, int nPts, int nObs, const int *iidx, const int *jidx, const int *ptr, RingPlanHost &out,
                     bool force = false);
 int launch_schur_ring(psba_ctx *h, double mu, bool dump);
+struct SchurLdsArgs;
+bool launch_schur_lds_mode(int mode, dim3 G, dim3 B, size_t lds, hipStream_t s, const SchurLdsArgs &a);  // kernels_schur_modes.hip
 #endif
 int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
@@ -346,6 +348,7 @@ int launch_pcg_solve(psba_ctx *h);
 // kernels_chol_graph.hip
 int launch_chol_graph(psba_ctx *h);
 int chol_dist_shape(psba_ctx *h, int *NB, int *blocked);
+int chol_dist_exchange_plan(int n32, int NB, int nranks, int JE, long long (*out)[4], int cap);
 int chol_dist_begin(psba_ctx *h);
 int chol_dist_superpanel(psba_ctx *h, int J);
 int chol_dist_block(psba_ctx *h, int B, double *buf_dev, int set);

@@ -53,8 +53,10 @@ int dots(psba_handle h, size_t nA, size_t nT, const double *const (&x)[K], const
 //     |P_U + s (P_B - P_U)|^2 = delta^2, the root s in [0, 1] of  (d.d) s^2 + 2 (u.d) s + (u.u - delta^2) = 0,
 //     d = P_B - P_U.
 // Returns |p|; p = alpha P_U + beta P_B.
+// dd = d.d and ud = u.d are summed over d itself (as the reference does, trust_region.cpp:574-586): formed from
+// u.u, u.b and b.b they lose their digits to cancellation when P_U is close to P_B, and dd divides the root.
 double tr_step(double uBu, double uBb, double bBb, double delta, double uu, double ub, double bb, double ug, double bg,
-               double &alpha, double &beta) {
+               double dd, double ud, double &alpha, double &beta) {
   double len;
   {
     const double det = uBu * bBb - uBb * uBb;  // Cramer on the 2x2 Gram system of B
@@ -73,9 +75,9 @@ double tr_step(double uBu, double uBb, double bBb, double delta, double uu, doub
       beta = 1;
       len = lb;
     } else {
-      const double dd = uu - 2 * ub + bb, ud = ub - uu, c = uu - delta * delta;
+      const double c = uu - delta * delta;
       double disc = ud * ud - dd * c;
-      if (disc < 0.25e-12) disc = 0;  // (the reference zeroes |b^2 - 4ac| < 1e-12; a negative value is rounding)
+      if (std::fabs(disc) < 0.25e-12) disc = 0;  // the reference zeroes |b^2 - 4ac| < 1e-12 (b = 2 ud); below that, NaN as there
       const double sgm = (-ud + std::sqrt(disc)) / dd;
       alpha = 1 - sgm;
       beta = sgm;
@@ -174,17 +176,18 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
     if (stop) break;
     TR_TRY(psba_jmul_dots(h, PU.data(), PB.data(), d3));  // :166-176
     const double uBu = 2 * d3[0], uBb = 2 * d3[1], bBb = 2 * d3[2];
-    double ip[5];  // u.u, u.b, b.b, u.g, b.g
+    double ip[7];  // u.u, u.b, b.b, u.g, b.g, d.d, u.d with d = P_B - P_U
     {
-      const double *const xs[5] = {PU.data(), PU.data(), PB.data(), PU.data(), PB.data()};
-      const double *const ys[5] = {PU.data(), PB.data(), PB.data(), g.data(), g.data()};
-      TR_TRY(dots<5>(h, nA, nT, xs, ys, ip));
+      for (size_t i = 0; i < nT; i++) P[i] = PB[i] - PU[i];  // (P is free here: it is rebuilt for every try below)
+      const double *const xs[7] = {PU.data(), PU.data(), PB.data(), PU.data(), PB.data(), P.data(), PU.data()};
+      const double *const ys[7] = {PU.data(), PB.data(), PB.data(), g.data(), g.data(), P.data(), P.data()};
+      TR_TRY(dots<7>(h, nA, nT, xs, ys, ip));
     }
     flag = PSBA_ITER_CONTINUE;
     while (flag == PSBA_ITER_CONTINUE) {  // :180-277
       tries++;
       double alpha, beta;
-      const double p_norm = tr_step(uBu, uBb, bBb, dk, ip[0], ip[1], ip[2], ip[3], ip[4], alpha, beta);
+      const double p_norm = tr_step(uBu, uBb, bBb, dk, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], alpha, beta);
       for (size_t i = 0; i < nT; i++) P[i] = alpha * PU[i] + beta * PB[i];
       TR_TRY(psba_set_step(h, P.data()));  // dp_buffer <- P, compute_newp (:183-187)
       double act = 0;

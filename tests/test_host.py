@@ -488,3 +488,37 @@ def test_bench_collective_bytes():
     c = b.collective_bytes(2000, 8, True)
     assert abs(c["allreduce_S_ea"] / 1e9 - 0.576) < 0.001
     assert abs(c["broadcast_factor_columns"] / 1e9 - 0.576) < 0.001
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+@pytest.mark.parametrize("n32,NB", [(2048, 256), (2080, 256), (12000, 384), (4128, 256), (1824, 256)])
+def test_sharded_factorization_exchange_plan(n32, NB, nranks):
+    """the RCCL column exchange of the sharded dense factorization (kernels_chol_graph.hip,
+    chol_dist_comm) has only ever run with one rank, where every block's owner is rank 0 and the unpack branch
+    never executes.  The owner / slot / length arithmetic it uses is one host function; here it is replayed for
+    2, 3 and 8 ranks (and n32 mod 64 = 32, where the last block is half a block) against the sequence the
+    three-handle GPU test performs by hand: every column >= the first super-panel's end travels exactly once, from
+    the rank that updated it (block B mod nranks), in front of the super-panel that needs it, packed rows from the
+    block's diagonal to the e_a row."""
+    from psba_amd import capi
+    assert n32 % 32 == 0
+    seen = {}
+    for J in range(0, n32, NB):
+        JE = J + NB
+        plan = capi.chol_dist_exchange_plan(n32, NB, nranks, JE)
+        want = [] if JE >= n32 else list(range(JE // 64, (min(JE + NB, n32) + 63) // 64))
+        assert [b for b, _, _, _ in plan] == want
+        for k, (B, owner, slot, doubles) in enumerate(plan):
+            assert owner == B % nranks and 0 <= owner < nranks
+            assert slot == k and slot <= NB // 64            # the exchange buffer has NB / 64 + 1 slots
+            cols = min(64, n32 - 64 * B)
+            assert cols in (32, 64) and doubles == (n32 + 1 - 64 * B) * cols
+            assert doubles <= (n32 + 1) * 64                 # fits a slot
+            assert B not in seen
+            seen[B] = JE
+    # every 64-column block right of the first super-panel is exchanged exactly once, before the super-panel that holds it
+    first = NB // 64 if NB % 64 == 0 else None
+    if first is not None and n32 > NB:
+        assert sorted(seen) == list(range(NB // 64, (n32 + 63) // 64))
+        for B, JE in seen.items():
+            assert JE <= 64 * B + 63 and 64 * B < JE + NB
