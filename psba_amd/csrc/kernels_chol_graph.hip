@@ -448,14 +448,19 @@ __device__ __forceinline__ void wide4_block(double *Lw, const double *Lx, int ld
 // owners send a super-panel's columns to everybody before it is factored (launch_chol_graph), and the
 // next diagonal block is factored after that exchange by k_cholg_diag (workgroup 0's look-ahead would
 // read columns this rank may not own).
+// part (round 4, the look-ahead of launch_chol_graph): 0 = the whole trailing triangle; 1 = only its first ncolb
+// 64-column blocks (the columns of the NEXT super-panel, all rows below) + workgroup 0's diagonal block and its
+// factorization; 2 = called with Tw moved past those columns: everything to their right, no workgroup 0 -- so
+// that the next super-panel's 32-column steps can run beside the bulk of this update on a second stream.
 __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *Lx, int ld, int J, int KW, int nT,
-                                                            int Tw, double *linv, int *status, int nranks, int rank) {
+                                                            int Tw, double *linv, int *status, int nranks, int rank,
+                                                            int part, int ncolb) {
   __shared__ Factor32Lds s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   if (blockIdx.x == 0) {
-    if (nranks > 0) return;
+    if (nranks > 0 || part == 2) return;
     if (tid < 4) s.flag[tid] = 0;
     if (tid == 4) s.fail = 0;
     if (wave < 3) {
@@ -473,26 +478,33 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
   // enough, the uneven patch counts per XCD cost more -- row-major block order it is)
   const int nTl = nT - 1 - Tw;                 // tile rows of the trailing square (without the e_a row)
   const long long MR = (nTl + 3) / 4;          // 64-row block rows
-  const long long ntri = MR * (MR + 1) / 2;
+  const long long ntri = part == 1 ? MR * ncolb : MR * (MR + 1) / 2;
   const long long idx = (long long)(blockIdx.x - 1) * 4 + wave;
   if (idx >= ntri) {
     const long long e = idx - ntri;  // e_a tile row
-    if (e >= nTl) return;
+    if (e >= nTl || (part == 1 && e >= 4 * ncolb)) return;
     if (nranks > 0 && (Tw + (int)e) / 4 % nranks != rank) return;
     const int TC = Tw + (int)e;
     store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
     return;
   }
-  int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-  while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
-  while ((long long)m * (m + 1) / 2 > idx) m--;
-  m = __builtin_amdgcn_readfirstlane(m);
-  const int mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+  int m, mc;
+  if (part == 1) {  // the first ncolb block columns, all block rows at or below the diagonal
+    m = __builtin_amdgcn_readfirstlane((int)(idx / ncolb));
+    mc = __builtin_amdgcn_readfirstlane((int)(idx % ncolb));
+    if (mc > m) return;
+  } else {
+    m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+    while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+    while ((long long)m * (m + 1) / 2 > idx) m--;
+    m = __builtin_amdgcn_readfirstlane(m);
+    mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+  }
   if (nranks > 0 && (Tw / 4 + mc) % nranks != rank) return;
   const int TR0 = Tw + 4 * m, TC0 = Tw + 4 * mc;
   const int last = nT - 2;  // last tile row / column of the square
-  // (sharded: nobody else forms the next diagonal block's tiles -- its owner does, here)
-  const int Tx = nranks > 0 ? -4 : Tw;
+  // (sharded, or the far part of a split update: nobody else forms the first diagonal block's tiles)
+  const int Tx = (nranks > 0 || part == 2) ? -4 : Tw;
   if (mc < m && TR0 + 3 <= last && (m > 0))
     wide4_block<true>(Lw, Lx, ld, J, KW, Tx, last, TR0, TC0, li, lk);
   else
@@ -1132,7 +1144,11 @@ static ChainShape chain_shape(const psba_ctx *h) {
 // one super-panel [J, J + NB) of the two-level chain: its 32-column steps, which update only the
 // super-panel's remaining columns (all rows below), then ONE K = NB update of everything to its
 // right.  nranks > 0: that update only for this rank's 64-column blocks (k_cholg_update_wide4); 0: replicated.
-static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, int J, int nranks, int rank) {
+// look = true: the K = NB update split in two (see k_cholg_update_wide4): the next super-panel's columns on
+// stream s, then -- on the side stream, between the events the caller manages -- everything to their right
+static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, int J, int nranks, int rank, bool look = false,
+                               hipStream_t side = nullptr, hipEvent_t ev_steps = nullptr, hipEvent_t ev_far_prev = nullptr,
+                               hipEvent_t ev_far = nullptr) {
   const int n32 = h->n32, ld = h->n32, nT = n32 / 16 + 1;
   double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
   const int NB = c.NB;
@@ -1161,11 +1177,28 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
       const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
       hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
                          JE - J, nT, Tw, linv, h->status);
+    } else if (look) {
+      const int ncolb = NB / 64;
+      const long long MR = (nT - 1 - Tw + 3) / 4;
+      (void)hipEventRecord(ev_steps, s);
+      if (ev_far_prev) (void)hipStreamWaitEvent(s, ev_far_prev, 0);  // its columns carry the previous update
+      const long long nnear = MR * ncolb + (4 * ncolb < nT - 1 - Tw ? 4 * ncolb : nT - 1 - Tw);
+      hipLaunchKernelGGL(k_cholg_update_wide4, dim3(1 + (unsigned)((nnear + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J, JE - J,
+                         nT, Tw, linv, h->status, 0, 0, 1, ncolb);
+      (void)hipStreamWaitEvent(side, ev_steps, 0);
+      const int Tw2 = Tw + 4 * ncolb;
+      if (Tw2 < nT - 1) {
+        const long long MR2 = (nT - 1 - Tw2 + 3) / 4;
+        const unsigned grid = 1 + (unsigned)((MR2 * (MR2 + 1) / 2 + (nT - 1 - Tw2) + 3) / 4);
+        hipLaunchKernelGGL(k_cholg_update_wide4, dim3(grid), dim3(256), 0, side, Lw, Lx, ld, J, JE - J, nT, Tw2, linv,
+                           h->status, 0, 0, 2, ncolb);
+      }
+      (void)hipEventRecord(ev_far, side);
     } else {
       const long long MR = (nT - 1 - Tw + 3) / 4;
       const unsigned grid = 1 + (unsigned)((MR * (MR + 1) / 2 + (nT - 1 - Tw) + 3) / 4);  // diag; 64x64 blocks, e_a tiles
       hipLaunchKernelGGL(k_cholg_update_wide4, dim3(grid), dim3(256), 0, s, Lw, Lx, ld, J, JE - J, nT, Tw, linv,
-                         h->status, nranks, rank);
+                         h->status, nranks, rank, 0, 0);
     }
   }
 }
@@ -1229,7 +1262,40 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   const int jl = n32 - GB * tail;  // the panel launches stop here
   if (!skip_diag && !(tail > 0 && jl == 0))  // else the S-reduce kernel has factored the first diagonal block already
     hipLaunchKernelGGL(k_cholg_diag, dim3(1), dim3(256), 0, s, Lw, Lx, ld, 0, linv, h->status, h->chol_tim);
-  for (int J = 0; blocked && J < n32; J += c.NB) enqueue_superpanel(h, s, c, J, 0, 0);
+  // Look-ahead (round 4; large matrices, single rank): the K = NB update of a super-panel is split -- the next
+  // super-panel's columns first, on this stream; everything to their right on a side stream, beside the next
+  // super-panel's ~12 small dependent launches (5 of the 17.6 ms of a 12 000 x 12 000 factorization were those
+  // launches with the chip otherwise idle).  A far update follows the previous one on its stream and the
+  // 32-column steps whose panel it applies (event); the near update waits for the previous far update, which
+  // wrote its columns.  PSBA_CHOL_LOOKAHEAD=0 / 1 forces it off / on (default: n32 >= 6000, wide4 kernel).
+  bool look = blocked && n32 >= 6000 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
+  if (const char *e = getenv("PSBA_CHOL_LOOKAHEAD")) look = blocked && atoi(e) != 0 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
+  if (look) {
+    if (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) look = false;
+    const size_t need = 2 * (size_t)(n32 / c.NB + 2);
+    while (look && h->chol_events.size() < need) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        look = false;
+        break;
+      }
+      h->chol_events.push_back(e);
+    }
+  }
+  {
+    hipEvent_t far_prev = nullptr;
+    int k = 0;
+    for (int J = 0; blocked && J < n32; J += c.NB, k++) {
+      if (!look) {
+        enqueue_superpanel(h, s, c, J, 0, 0);
+        continue;
+      }
+      const bool has_update = J + c.NB < n32;
+      enqueue_superpanel(h, s, c, J, 0, 0, true, h->stream2, h->chol_events[2 * k], far_prev, h->chol_events[2 * k + 1]);
+      if (has_update) far_prev = h->chol_events[2 * k + 1];
+    }
+    if (far_prev) (void)hipStreamWaitEvent(s, far_prev, 0);  // the backward solve (and whoever comes next) behind the last far update
+  }
   for (int j = 0; !blocked && j < n32; j += GB) {
     const bool last = j + GB >= n32;
     const int T0 = (j + GB) / 16;

@@ -225,6 +225,7 @@ int psba_destroy(psba_handle h) {
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->k3_event) (void)hipEventDestroy(h->k3_event);
+  for (hipEvent_t e : h->chol_events) (void)hipEventDestroy(e);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   free_problem_buffers(h);
   dev_free(h->scal);

@@ -800,13 +800,17 @@ def test_backward_solve_variants(monkeypatch, one_wg):
 
 
 @pytest.mark.parametrize("n_cams", [130, 203])
-def test_two_level_blocked_panel_chain(monkeypatch, n_cams):
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_two_level_blocked_panel_chain(monkeypatch, n_cams, lookahead):
     """PSBA_CHOL_BLOCKED=1 forces the chain large matrices take (super-panels of 128 columns:
     32-column steps that update the super-panel's own columns, one K = 128 update of the rest) at
-    sizes the oracle solves quickly; 203 cameras end in a partial super-panel."""
+    sizes the oracle solves quickly; 203 cameras end in a partial super-panel.  lookahead: round 4's split of
+    that update (the next super-panel's columns first, the rest on a side stream beside the next super-panel's
+    steps: default from n32 = 6000, forced here with PSBA_CHOL_LOOKAHEAD=1)."""
     import psba_amd
     import psba_amd.synth as synth
     monkeypatch.setenv("PSBA_CHOL_BLOCKED", "1")
+    monkeypatch.setenv("PSBA_CHOL_LOOKAHEAD", "1" if lookahead else "0")
     monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")  # (the two-level chain is a form of the unfused one: blocked = !fused && ...)
     prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=300 + n_cams)
     o = Oracle(prob)
