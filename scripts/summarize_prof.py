@@ -23,9 +23,13 @@ for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"))
         pmc.setdefault(k, {})[counter] = sum(v) / len(v)
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 
+cmd = ("scripts/profile.sh", "bench.py --steps 20 --warmup 3 --no-cpu-baseline")
+if "--cfg5-full" in sys.argv:
+    cmd = ("scripts/profile_cfg5_full.sh", "bench.py --workload cfg5 --cfg5-points 2000000 --steps 3 --warmup 0 --segment 3 "
+           "--spread-segments 0 --no-cpu-baseline")
 lines = [f"# rocprofv3 summary {out}", "",
-         "Command (scripts/profile.sh, on the MI355X box): `rocprofv3 --kernel-trace --stats -f csv -- python3 "
-         "bench.py --steps 20 --warmup 3 --no-cpu-baseline`; FETCH_SIZE and WRITE_SIZE from two further "
+         f"Command ({cmd[0]}, on the MI355X box): `rocprofv3 --kernel-trace --stats -f csv -- python3 "
+         f"{cmd[1]}`; FETCH_SIZE and WRITE_SIZE from two further "
          "`--pmc` passes of the same command.", "",
          f"Workload: {bench['config']['workload']} ({bench['config']['n_cams']} cameras, {bench['config']['n_pts']} points, "
          f"{bench['config']['n_obs']} observations), {bench['steps']} LM iterations, {bench['damping_tries']} damping tries.",
