@@ -87,6 +87,22 @@ int psba_reset_params(psba_handle h);
 /* read back the current (PSBA_PARAMS_CUR) or proposed (PSBA_PARAMS_NEW) parameters */
 int psba_get_params(psba_handle h, int which, double *camsEx, double *pts3D);
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs);
+
+/* ---- free intrinsics ---------------------------------------------------------------
+ * The reference's driver reads 11 parameters per camera -- (fu, u0, v0, ar, s), quaternion -> local rotation,
+ * translation (PSBA/main.cpp:73,140-149; data/54camsvarK.txt) -- and then strips the intrinsics: its kernels
+ * optimise six (CL_files/PSBA.cl:5-7).  PSBA_CAMERA_FREE_K optimises all eleven: the camera block becomes
+ * (fu, u0, v0, ar, s | v0, v1, v2 | t0, t1, t2), nA = 11 nCams, dp = [11 per camera ; 3 per point].
+ * psba_upload_problem takes the same arrays (Kparas and camsEx are joined inside); psba_get_params /
+ * psba_set_params then move 11 doubles per camera.  One plain route (kernels_freek.hip: global-atomic assembly,
+ * the generic dense factorization), single rank, dense solver; the fused verbs and psba_levmar work, the
+ * sba_func.h mirror, the trust-region operators and psba_solve return PSBA_E_STATE.  The reference has no
+ * arithmetic for this (it never implemented it): PARITY UNPINNED -- checked against the oracle's twin, finite
+ * differences and a dense solve of the full normal equations.  Before psba_upload_problem. */
+#define PSBA_CAMERA_FIXED_K 0
+#define PSBA_CAMERA_FREE_K 1
+int psba_set_camera_model(psba_handle h, int model);
+int psba_camera_block(psba_handle h, int *cnp); /* 6 or 11 */
 /* which S-assembly route the uploaded problem takes: 0 = LDS-resident partitions of the block
  * triangle with the static schedule (fewer than 2048 cameras, up to 8 GB of partial-sum slabs on
  * this rank), 1 = the owner route for larger problems (one thread per block segment,

@@ -1043,3 +1043,152 @@ done:
   free(g); free(eab); free(PU); free(PB); free(P); free(Jx1); free(Jx2); free(newcams); free(newpts); free(exn);
   return flag;
 }
+
+/* ---- free intrinsics: camera block (fu, u0, v0, ar, s | v | t), 11 parameters -----------------
+ * The reference reads this layout (PSBA/main.cpp:73,140-149; data/54camsvarK.txt) and never optimises the first
+ * five (CL_files/PSBA.cl:5-7): there is no reference arithmetic, so this twin is PARITY UNPINNED.  It is written
+ * differently from the HIP route on purpose -- the Jacobian of the intrinsics by its closed form here, checked by
+ * central differences in tests/test_freek.py; the normal equations as ONE dense (11 nC + 3 nP)^2 matrix J^T J + mu I
+ * solved by a plain Cholesky, no Schur complement -- so that the GPU's block elimination has an independent judge. */
+#define FK 11
+static void fk_project(const double *cam, const double *q0, const double *M, double *xy, double *P) {
+  double q[4];
+  compose_quat(q0, cam + 5, q);
+  quat_rotate(q, M, P);
+  for (int c = 0; c < 3; c++) P[c] += cam[8 + c];
+  project(cam, P, xy);
+}
+
+/* ex[2 nO] = measured - projected */
+void orc_fk_exQT(int nO, const double *impts, const double *initrot, const double *cams11, const double *pts,
+                 const int *iidx, const int *jidx, double *ex) {
+  for (int a = 0; a < nO; a++) {
+    double xy[2], P[3];
+    fk_project(cams11 + FK * jidx[a], initrot + 4 * jidx[a], pts + 3 * iidx[a], xy, P);
+    ex[2 * a] = impts[2 * a] - xy[0];
+    ex[2 * a + 1] = impts[2 * a + 1] - xy[1];
+  }
+}
+
+/* JA[22 nO] (2 x 11 row-major), JB[6 nO]: the six extrinsic columns and B from the six-parameter Jacobian with
+ * this camera's K, the five intrinsic columns in closed form */
+void orc_fk_jacobi(int nO, const double *initrot, const double *cams11, const double *pts, const int *iidx,
+                   const int *jidx, double *JA, double *JB) {
+  for (int a = 0; a < nO; a++) {
+    const int i = iidx[a], j = jidx[a], one = 0;
+    const double *cam = cams11 + FK * j;
+    double A6[12], xy[2], P[3];
+    orc_compute_jacobiQT(1, cam, initrot + 4 * j, cam + 5, pts + 3 * i, &one, &one, A6, JB + 6 * a);
+    fk_project(cam, initrot + 4 * j, pts + 3 * i, xy, P);
+    const double xn = P[0] / P[2], yn = P[1] / P[2];
+    double *A = JA + 2 * FK * a;
+    A[0] = xn; A[1] = 1; A[2] = 0; A[3] = 0; A[4] = yn;
+    A[FK + 0] = cam[3] * yn; A[FK + 1] = 0; A[FK + 2] = 1; A[FK + 3] = cam[0] * yn; A[FK + 4] = 0;
+    for (int k = 0; k < 6; k++) {
+      A[5 + k] = A6[k];
+      A[FK + 5 + k] = A6[6 + k];
+    }
+  }
+}
+
+/* N = J^T J (dense, nT x nT, nT = 11 nC + 3 nP) and g = J^T e; returns ||e||^2 */
+double orc_fk_normal(int nC, int nP, int nO, const double *impts, const double *initrot, const double *cams11,
+                     const double *pts, const int *iidx, const int *jidx, double *N, double *g) {
+  const int nA = FK * nC, nT = nA + 3 * nP;
+  double *JA = (double *)xmalloc(sizeof(double) * 2 * FK * (size_t)nO), *JB = (double *)xmalloc(sizeof(double) * 6 * (size_t)nO);
+  double *ex = (double *)xmalloc(sizeof(double) * 2 * (size_t)nO);
+  orc_fk_jacobi(nO, initrot, cams11, pts, iidx, jidx, JA, JB);
+  orc_fk_exQT(nO, impts, initrot, cams11, pts, iidx, jidx, ex);
+  memset(N, 0, sizeof(double) * (size_t)nT * nT);
+  memset(g, 0, sizeof(double) * (size_t)nT);
+  double cost = 0;
+  for (int a = 0; a < nO; a++) {
+    int col[FK + 3];
+    double row[2][FK + 3];
+    for (int k = 0; k < FK; k++) {
+      col[k] = FK * jidx[a] + k;
+      row[0][k] = JA[2 * FK * a + k];
+      row[1][k] = JA[2 * FK * a + FK + k];
+    }
+    for (int k = 0; k < 3; k++) {
+      col[FK + k] = nA + 3 * iidx[a] + k;
+      row[0][FK + k] = JB[6 * a + k];
+      row[1][FK + k] = JB[6 * a + 3 + k];
+    }
+    for (int r = 0; r < FK + 3; r++) {
+      g[col[r]] += row[0][r] * ex[2 * a] + row[1][r] * ex[2 * a + 1];
+      for (int c = 0; c < FK + 3; c++) N[(size_t)col[r] * nT + col[c]] += row[0][r] * row[0][c] + row[1][r] * row[1][c];
+    }
+    cost += ex[2 * a] * ex[2 * a] + ex[2 * a + 1] * ex[2 * a + 1];
+  }
+  free(JA); free(JB); free(ex);
+  return cost;
+}
+
+/* levmar() (PSBA/levmar.cpp:45-256: same damping schedule, gain ratio and stop tests) on the 11-parameter blocks,
+ * every step from the DENSE damped normal equations.  Small problems only (nT^3 / 3 flops per try). */
+int orc_fk_levmar(int nC, int nP, int nO, const double *impts, const double *initrot, double *cams11, double *pts,
+                  const int *iidx, const int *jidx, const orc_lm_opts *opts, orc_lm_result *res, double *log) {
+  const int nA = FK * nC, nB = 3 * nP, nT = nA + nB;
+  const double STOP = 1e-12, EPS_SQ = 1e-24;
+  double *N = (double *)xmalloc(sizeof(double) * (size_t)nT * nT), *Nd = (double *)xmalloc(sizeof(double) * (size_t)nT * nT);
+  double *g = (double *)xmalloc(sizeof(double) * nT), *dp = (double *)xmalloc(sizeof(double) * nT);
+  double *nc = (double *)xmalloc(sizeof(double) * nA), *np_ = (double *)xmalloc(sizeof(double) * nB);
+  double *ex = (double *)xmalloc(sizeof(double) * 2 * (size_t)nO);
+  double mu = 0, p_L2 = 1e3, ex_L2 = 0;
+  int nu = 2, tries = 0, nlog = 0, flag = 3, itno = 0;
+  memset(res, 0, sizeof *res);
+  for (; itno < opts->max_iter && flag == 3; itno++) {
+    ex_L2 = orc_fk_normal(nC, nP, nO, impts, initrot, cams11, pts, iidx, jidx, N, g);
+    if (itno == 0) {
+      res->init_err = ex_L2;
+      double mx = 0;
+      for (int t = 0; t < nT; t++) mx = N[(size_t)t * nT + t] > mx ? N[(size_t)t * nT + t] : mx;
+      mu = (opts->init_mu != 0.0 ? opts->init_mu : 1e-3) * mx;
+      res->mu0 = mu;
+    }
+    while (1) {
+      tries++;
+      memcpy(Nd, N, sizeof(double) * (size_t)nT * nT);
+      for (int t = 0; t < nT; t++) Nd[(size_t)t * nT + t] += mu;
+      const double bad = orc_chol_solve(nT, Nd, g, dp);
+      if (bad == 0.0) {
+        double dp_L2 = 0, den = 0, newp = 0;
+        for (int t = 0; t < nT; t++) {
+          dp_L2 += dp[t] * dp[t];
+          den += dp[t] * (mu * dp[t] + g[t]);
+        }
+        if (dp_L2 < p_L2 * STOP * STOP) { flag = 5; break; }
+        if (dp_L2 >= (p_L2 + STOP) / EPS_SQ) { flag = 4; break; }
+        for (int t = 0; t < nA; t++) { nc[t] = cams11[t] + dp[t]; newp += nc[t] * nc[t]; }
+        for (int t = 0; t < nB; t++) { np_[t] = pts[t] + dp[nA + t]; newp += np_[t] * np_[t]; }
+        orc_fk_exQT(nO, impts, initrot, nc, np_, iidx, jidx, ex);
+        double new_L2 = 0;
+        for (int t = 0; t < 2 * nO; t++) new_L2 += ex[t] * ex[t];
+        const double rho = (ex_L2 - new_L2) / den;
+        if (log && nlog < opts->log_cap) {
+          double *row = log + 5 * nlog++;
+          row[0] = itno; row[1] = new_L2; row[2] = rho; row[3] = mu; row[4] = rho > 0;
+        }
+        if (rho > 0) {
+          double tmp = 2 * rho - 1;
+          tmp = 1.0 - tmp * tmp * tmp;
+          mu *= tmp >= 1.0 / 3.0 ? tmp : 1.0 / 3.0;
+          nu = 2;
+          memcpy(cams11, nc, sizeof(double) * nA);
+          memcpy(pts, np_, sizeof(double) * nB);
+          p_L2 = newp;
+          ex_L2 = new_L2;
+          break;
+        }
+      }
+      mu *= nu;
+      if (2.0 * nu > 1e9) { flag = 4; break; }
+      nu *= 2;
+    }
+    if (ex_L2 <= STOP) flag = 6;
+  }
+  res->flag = flag; res->iters = itno; res->tries = tries; res->final_err = ex_L2; res->n_log = nlog;
+  free(N); free(Nd); free(g); free(dp); free(nc); free(np_); free(ex);
+  return flag;
+}

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["psba_api.cpp", "schur_plan.cpp", "lm_loop.cpp", "tr_loop.cpp", "sba_io.cpp", "kernels_linearize.hip",
            "kernels_tr.hip",
-           "kernels_schur.hip", "kernels_chol.hip", "kernels_pcg.hip", "kernels_chol_graph.hip", "kernels_backsub.hip"]
+           "kernels_schur.hip", "kernels_freek.hip", "kernels_chol.hip", "kernels_pcg.hip", "kernels_chol_graph.hip", "kernels_backsub.hip"]
 # PSBA_BUILD_EXPERIMENTS=1: also the rejected experiments (round 3's K2 ring route) and their test hooks
 EXPERIMENTS = bool(os.environ.get("PSBA_BUILD_EXPERIMENTS"))
 if EXPERIMENTS:

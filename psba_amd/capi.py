@@ -140,6 +140,8 @@ SIGNATURES = [
     ("psba_set_sparse_S", C.c_int, [_h, _dp, _dp]),
     ("psba_sparse_pattern", C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
     ("psba_set_sparse_pattern", C.c_int, [_h, C.POINTER(C.c_ubyte), C.c_longlong]),
+    ("psba_set_camera_model", C.c_int, [_h, C.c_int]),
+    ("psba_camera_block", C.c_int, [_h, _ip]),
     ("psba_chol_dist_exchange_plan", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_int]),
     ("psba_chol_dist_shape", C.c_int, [_h, _ip, _ip, _ip]),
     ("psba_chol_dist_begin", C.c_int, [_h]),
@@ -384,9 +386,19 @@ class Psba:
         return rc
 
     # ---- setup ----
+    def set_camera_model(self, free_k):
+        """PSBA_CAMERA_FREE_K: camera blocks of 11 (fu, u0, v0, ar, s | rotation | translation); before upload."""
+        self._ck(lib.psba_set_camera_model(self._h, 1 if free_k else 0))
+
+    def camera_block(self):
+        n = C.c_int()
+        self._ck(lib.psba_camera_block(self._h, C.byref(n)))
+        return n.value
+
     def upload_problem(self, prob):
         self.nC, self.nP, self.nO = int(prob["nC"]), int(prob["nP"]), int(prob["nO"])
-        self.nA, self.nB = 6 * self.nC, 3 * self.nP
+        self.cnp = self.camera_block()
+        self.nA, self.nB = self.cnp * self.nC, 3 * self.nP
         self.nT = self.nA + self.nB
         a = [_c(prob[k]).reshape(-1) for k in ("K", "impts", "initrot", "cams", "pts")]
         ii, jj = _c(prob["iidx"], np.int32), _c(prob["jidx"], np.int32)
@@ -403,7 +415,7 @@ class Psba:
     def get_params(self, which=PARAMS_CUR):
         c, p = np.empty(self.nA), np.empty(self.nB)
         self._ck(lib.psba_get_params(self._h, which, _d(c), _d(p)))
-        return c.reshape(self.nC, 6), p.reshape(self.nP, 3)
+        return c.reshape(self.nC, self.cnp), p.reshape(self.nP, 3)
 
     # ---- fused verbs ----
     def schur_path(self):

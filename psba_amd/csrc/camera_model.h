@@ -60,8 +60,9 @@ PSBA_HD void residual_obs(const double *K, const double *q0, const double *cam, 
 }
 
 // residual + Jacobian blocks
+// xn: (optional) the normalised image coordinates (Px / Pz, Py / Pz): what d(x, y) / dK needs
 PSBA_HD void linearize_obs(const double *K, const double *q0, const double *cam, const double *M,
-                           double mx, double my, double *e, double *A, double *B) {
+                           double mx, double my, double *e, double *A, double *B, double *xn = nullptr) {
   double sl, R[9];
   const Quat q = compose_quat(q0, cam[0], cam[1], cam[2], sl);
   quat_matrix(q, R);
@@ -73,6 +74,10 @@ PSBA_HD void linearize_obs(const double *K, const double *q0, const double *cam,
   const double y = (K[0] * K[3] * Py + K[2] * Pz) * inv;
   e[0] = mx - x;
   e[1] = my - y;
+  if (xn) {
+    xn[0] = Px * inv;
+    xn[1] = Py * inv;
+  }
   // D = d(x,y)/dP
   const double d00 = K[0] * inv, d01 = K[4] * inv, d02 = (K[1] - x) * inv;
   const double d11 = K[0] * K[3] * inv, d12 = (K[2] - y) * inv;
@@ -121,6 +126,33 @@ PSBA_HD void linearize_obs(const double *K, const double *q0, const double *cam,
     const double dP2 = 2.0 * (du2 * udM + q.u2 * dudM + g * M[2] + ds * c2 + q.s * m2);
     A[k] = d00 * dP0 + d01 * dP1 + d02 * dP2;
     A[6 + k] = d11 * dP1 + d12 * dP2;
+  }
+}
+
+// Free intrinsics (the reference reads 11 parameters per camera, PSBA/main.cpp:73,140-149, and never
+// optimises the first five, CL_files/PSBA.cl:5-7): camera block p = (fu, u0, v0, ar, s | v0, v1, v2 | t0, t1, t2).
+// x = fu xn + s yn + u0, y = fu ar yn + v0 with (xn, yn) = (Px, Py) / Pz, so
+//   d(x, y) / d(fu, u0, v0, ar, s) = [ xn, 1, 0, 0, yn ;  ar yn, 0, 1, fu yn, 0 ]
+// and the other six columns are those of the fixed-K Jacobian.  A is 2 x 11 row-major.
+constexpr int FK_CNP = 11;
+PSBA_HD void linearize_obs_freek(const double *p, const double *q0, const double *M, double mx, double my, double *e,
+                                 double *A, double *B) {
+  double A6[12], xn[2];
+  linearize_obs(p, q0, p + 5, M, mx, my, e, A6, B, xn);
+  A[0] = xn[0];
+  A[1] = 1.0;
+  A[2] = 0.0;
+  A[3] = 0.0;
+  A[4] = xn[1];
+  A[FK_CNP + 0] = p[3] * xn[1];
+  A[FK_CNP + 1] = 0.0;
+  A[FK_CNP + 2] = 1.0;
+  A[FK_CNP + 3] = p[0] * xn[1];
+  A[FK_CNP + 4] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    A[5 + k] = A6[k];
+    A[FK_CNP + 5 + k] = A6[6 + k];
   }
 }
 

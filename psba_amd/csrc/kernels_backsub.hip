@@ -319,6 +319,7 @@ int launch_publish_scal(psba_ctx *h, hipStream_t s) {
 }
 
 int launch_backsub(psba_ctx *h, double mu, bool dump) {
+  if (h->cnp != 6) return dump ? fail(h, PSBA_E_STATE, "the sba_func.h mirror is six-parameter only") : launch_backsub_fk(h, mu);
   const Dims &d = h->d;
   BackArgs a;
   a.W = h->W;

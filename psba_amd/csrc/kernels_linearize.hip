@@ -581,6 +581,7 @@ __global__ __launch_bounds__(256) void k_max_diag(const double *U, const double 
 }
 
 int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
+  if (h->cnp != 6) return dump ? fail(h, PSBA_E_STATE, "the sba_func.h mirror is six-parameter only") : launch_linearize_fk(h, ahead, publish);
   const Dims &d = h->d;
   LinArgs a;
   a.camconst = h->camconst;
@@ -675,6 +676,7 @@ int launch_linearize(psba_ctx *h, bool dump, bool ahead, bool publish) {
 }
 
 int launch_residual(psba_ctx *h, int which, double *ex_out_dev) {
+  if (h->cnp != 6) return ex_out_dev ? fail(h, PSBA_E_STATE, "the sba_func.h mirror is six-parameter only") : launch_residual_fk(h, which);
   const Dims &d = h->d;
   const int set = which == PSBA_PARAMS_NEW ? 1 - h->cur : h->cur;
   PSBA_HIP(h, hipMemsetAsync(h->scal + SC_COST, 0, sizeof(double), h->stream));
@@ -691,6 +693,7 @@ int launch_residual(psba_ctx *h, int which, double *ex_out_dev) {
 }
 
 int launch_max_diag(psba_ctx *h) {
+  if (h->cnp != 6) return launch_max_diag_fk(h);
   PSBA_HIP(h, hipMemsetAsync(h->scal + SC_MAXDIAG, 0, sizeof(double), h->stream));
   int grid = (h->d.nP + 255) / 256;
   if (grid > 512) grid = 512;

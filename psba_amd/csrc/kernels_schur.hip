@@ -708,6 +708,7 @@ static int launch_schur_sparse(psba_ctx *h, double mu) {
 }
 
 int launch_schur(psba_ctx *h, double mu, bool dump) {
+  if (h->cnp != 6) return dump ? fail(h, PSBA_E_STATE, "the sba_func.h mirror is six-parameter only") : launch_schur_fk(h, mu);
   h->try_id++;
   h->diag_done = false;
   h->packed_pending = false;  // status words are generation stamps: nothing to zero

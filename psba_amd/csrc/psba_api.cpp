@@ -248,6 +248,20 @@ int psba_schur_path(psba_handle h, int *path) {
   return PSBA_OK;
 }
 
+int psba_set_camera_model(psba_handle h, int model) {
+  CHECK_H(h);
+  if (model != PSBA_CAMERA_FIXED_K && model != PSBA_CAMERA_FREE_K) return fail(h, PSBA_E_INVALID, "unknown camera model %d", model);
+  NEED(h, !h->uploaded, "psba_set_camera_model before psba_upload_problem (every buffer depends on the camera block)");
+  h->cnp = model == PSBA_CAMERA_FREE_K ? 11 : 6;
+  return PSBA_OK;
+}
+
+int psba_camera_block(psba_handle h, int *cnp) {
+  CHECK_H(h);
+  if (cnp) *cnp = h->cnp;
+  return PSBA_OK;
+}
+
 int psba_get_dims(psba_handle h, int *nCams, int *n3Dpts, int *n2Dprojs) {
   CHECK_H(h);
   NEED(h, h->uploaded, "no problem uploaded");
@@ -307,7 +321,10 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   d.nC = nCams;
   d.nP = n3Dpts;
   d.nO = n2Dprojs;
-  d.nA = 6 * nCams;
+  const int cnp = h->cnp;  // 6, or 11 with free intrinsics (kernels_freek.hip)
+  if (cnp != 6 && (h->solver == PSBA_SOLVER_PCG || h->nranks > 1 || h->comm))
+    return fail(h, PSBA_E_INVALID, "free intrinsics: dense solver, single rank only");
+  d.nA = cnp * nCams;
   d.nB = 3 * n3Dpts;
   d.nT = d.nA + d.nB;
   d.nTilesAll = (int)tile_pt.size() - 1;
@@ -321,7 +338,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   // camera-major pass beyond (~40 us flat; the LDS form takes 55 us at 257 cameras and 64 at 455,
   // where it ends: PSBA_LIN_LDS_ACC=1 keeps it up to there)
   const size_t cam_lds_max = getenv("PSBA_LIN_LDS_ACC") ? 96 * 1024 : 48 * 1024;
-  h->cam_global = (size_t)CAM_ACC * nCams * sizeof(double) > cam_lds_max || getenv("PSBA_LIN_GLOBAL_ACC");
+  h->cam_global = cnp == 6 && ((size_t)CAM_ACC * nCams * sizeof(double) > cam_lds_max || getenv("PSBA_LIN_GLOBAL_ACC"));
   h->d = d;
   h->nPart = d.nTiles < 768 ? d.nTiles : 768;  // persistent workgroups: three per CU fit since W is staged in halves
   if (const char *e = getenv("PSBA_LIN_GRID")) h->nPart = atoi(e) > 0 && atoi(e) < d.nTiles ? atoi(e) : d.nTiles;
@@ -349,20 +366,21 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     TRY(dev_alloc(h, &h->long_pts, long_pts.size()));
     PSBA_HIP(h, hipMemcpy(h->long_pts, long_pts.data(), sizeof(int) * long_pts.size(), hipMemcpyHostToDevice));
   }
-  TRY(dev_alloc(h, &h->W, (size_t)18 * d.nO));
-  TRY(dev_alloc(h, &h->W_alt, (size_t)18 * d.nO));
+  TRY(dev_alloc(h, &h->W, (size_t)3 * cnp * d.nO));
+  TRY(dev_alloc(h, &h->W_alt, (size_t)3 * cnp * d.nO));
   TRY(dev_alloc(h, &h->PV, (size_t)9 * d.nP));
   TRY(dev_alloc(h, &h->PV_alt, (size_t)9 * d.nP));
   // (a point without observations is never written by K1, whose stores come from the last lane of a point's run
   // of observations: its V_i and g_b,i are the zeros put here)
   PSBA_HIP(h, hipMemsetAsync(h->PV, 0, sizeof(double) * 9 * (size_t)d.nP, h->stream));
   PSBA_HIP(h, hipMemsetAsync(h->PV_alt, 0, sizeof(double) * 9 * (size_t)d.nP, h->stream));
-  TRY(dev_alloc(h, &h->U, (size_t)36 * d.nC));
-  TRY(dev_alloc(h, &h->U_alt, (size_t)36 * d.nC));
+  TRY(dev_alloc(h, &h->U, (size_t)cnp * cnp * d.nC));
+  TRY(dev_alloc(h, &h->U_alt, (size_t)cnp * cnp * d.nC));
   TRY(dev_alloc(h, &h->ga, (size_t)d.nA));
   TRY(dev_alloc(h, &h->ga_alt, (size_t)d.nA));
   h->ahead = h->lin_is_ahead = false;
-  TRY(dev_alloc(h, &h->campart, h->cam_global ? 1 : (size_t)(h->nPart + 1) * d.nC * CAM_ACC));  // (+1: the long points' slab)
+  TRY(dev_alloc(h, &h->campart, (h->cam_global || cnp != 6) ? 1 : (size_t)(h->nPart + 1) * d.nC * CAM_ACC));  // (+1: the long points' slab)
+  if (cnp != 6) TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * (cnp * (cnp + 1) / 2 + cnp)));  // kernels_freek.hip: 66 + 11 sums per camera
   if (h->cam_global) {
     TRY(dev_alloc(h, &h->camacc, (size_t)d.nC * CAM_ACC));
     // camera-major index of the observations, cut into segments of at most 256
@@ -521,7 +539,9 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     }
   }
 #endif
-  if (!sparse && !h->ring_nWg) {
+  if (cnp != 6) {
+    h->nGroups = 0;  // the free-intrinsics route needs no schedule (global atomics straight into S)
+  } else if (!sparse && !h->ring_nWg) {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
     if (h->nGroups) {
@@ -581,6 +601,15 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
   };
   PSBA_HIP(h, H2D(h->camconst, cc.data(), sizeof(double) * cc.size()));
+  std::vector<double> cam11;  // free intrinsics: the camera block is (K | local rotation | translation)
+  if (cnp != 6) {
+    cam11.resize((size_t)d.nA);
+    for (int j = 0; j < nCams; j++) {
+      for (int k = 0; k < 5; k++) cam11[(size_t)cnp * j + k] = Kparas[5 * j + k];
+      for (int k = 0; k < 6; k++) cam11[(size_t)cnp * j + 5 + k] = camsEx[6 * j + k];
+    }
+    camsEx = cam11.data();
+  }
   PSBA_HIP(h, H2D(h->cams[0], camsEx, sizeof(double) * d.nA));
   PSBA_HIP(h, H2D(h->pts[0], pts3D, sizeof(double) * d.nB));
   PSBA_HIP(h, H2D(h->params0, camsEx, sizeof(double) * d.nA));
@@ -994,6 +1023,7 @@ static int ensure_trv(psba_ctx *h) {
 
 int psba_jmul_dots(psba_handle h, const double *x1, const double *x2, double dots[3]) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   if (!x1 || !dots) return fail(h, PSBA_E_INVALID, "psba_jmul_dots: null pointer");
   TRY(ensure_trv(h));
@@ -1086,6 +1116,7 @@ int psba_allreduce_scalars(psba_handle h, double *v, int n) {
 
 int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   if (!x) return fail(h, PSBA_E_INVALID, "psba_compute_Jmultiply: null pointer");
   TRY(ensure_trv(h));
@@ -1097,6 +1128,7 @@ int psba_compute_Jmultiply(psba_handle h, const double *x, double *Jmul) {
 
 int psba_get_gradient(psba_handle h, double *g) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->linearized, "psba_linearize first");
   if (!g) return PSBA_E_INVALID;
   TRY(ensure_trv(h));
@@ -1114,6 +1146,7 @@ int psba_get_dp(psba_handle h, double *dp) {
 
 int psba_set_step(psba_handle h, const double *dp) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   if (!dp) return PSBA_E_INVALID;
   PSBA_HIP(h, hipMemcpyAsync(h->dp, dp, sizeof(double) * (size_t)h->d.nT, hipMemcpyHostToDevice, h->stream));
@@ -1125,6 +1158,7 @@ int psba_set_step(psba_handle h, const double *dp) {
 
 int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   if (h->nranks > 1 && !h->comm)
     return fail(h, PSBA_E_INVALID, "psba_cholmod_lambda on a rank layout needs the communicator (S must be complete)");
@@ -1204,6 +1238,7 @@ int psba_compute_jacobiQT(psba_handle h, double *jac_A, double *jac_B) {
 
 int psba_compute_U(psba_handle h, double coeff, double *out) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   h->coeff = coeff;
   TRY(relinearize_dump(h));
@@ -1226,6 +1261,7 @@ static int download_V(psba_ctx *h, double *out, double mu) {
 
 int psba_compute_V(psba_handle h, double coeff, double *out) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   h->coeff = coeff;
   TRY(relinearize_dump(h));
@@ -1236,6 +1272,7 @@ int psba_maxElmOfUV(psba_handle h, double *out) { return psba_max_diag(h, out); 
 
 int psba_update_UV(psba_handle h, double mu, double *U, double *V) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->linearized, "linearise first");
   h->mu = mu;
   h->mu_applied = true;
@@ -1262,6 +1299,7 @@ int psba_compute_Vinv(psba_handle h, double *Vinv) {
 
 int psba_compute_Wblks(psba_handle h, double coeff, double *Wblks) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   h->coeff = coeff;
   TRY(relinearize_dump(h));
@@ -1286,6 +1324,7 @@ int psba_compute_S(psba_handle h, double *S) {
 
 int psba_compute_g(psba_handle h, double coeff, double *g) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->uploaded, "no problem uploaded");
   h->coeff_g = coeff;
   TRY(relinearize_dump(h));
@@ -1408,6 +1447,7 @@ int psba_comm_init(psba_handle h, int nranks, int rank, const void *id128) {
 
 int psba_set_rank_layout(psba_handle h, int nranks, int rank) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6 || nranks <= 1, "free intrinsics: single rank only");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSBA_E_INVALID, "bad rank %d / %d", rank, nranks);
   if (h->comm) return fail(h, PSBA_E_STATE, "a communicator is attached: its layout is fixed");
   if (h->solver == PSBA_SOLVER_PCG && h->uploaded && nranks != h->nranks)
@@ -1441,6 +1481,7 @@ int psba_get_reduce_buffer(psba_handle h, double *out) {
 
 int psba_set_reduce_buffer(psba_handle h, const double *in) {
   CHECK_H(h);
+  NEED(h, h->cnp == 6, "six-parameter camera blocks only (free intrinsics: the fused verbs and psba_levmar)");
   NEED(h, h->assembled, "psba_schur_assemble first");
   NEED(h, !h->comm, "the reduce-buffer verbs are for handles without a communicator");
   if (!in) return fail(h, PSBA_E_INVALID, "null buffer");

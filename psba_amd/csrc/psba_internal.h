@@ -229,6 +229,7 @@ struct psba_ctx {
 #endif
   // block-sparse S + preconditioned CG (psba_set_solver, kernels_pcg.hip)
   int solver = 0;               // PSBA_SOLVER_*
+  int cnp = 6;  // parameters per camera: 6 (fixed intrinsics, the reference's kernels) or 11 (psba_set_camera_model: free intrinsics)
   double pcg_tol = 1e-10;
   int pcg_maxit = 500, pcg_iters = 0;
   double pcg_relres = 0.0;
@@ -343,6 +344,12 @@ int launch_schur(psba_ctx *h, double mu, bool dump);
 int launch_schur_expand(psba_ctx *h);
 // kernels_chol.hip
 int launch_chol_solve(psba_ctx *h);
+// kernels_freek.hip: the 11-parameter camera block (free intrinsics), one plain route
+int launch_linearize_fk(psba_ctx *h, bool ahead, bool publish);
+int launch_residual_fk(psba_ctx *h, int which);
+int launch_max_diag_fk(psba_ctx *h);
+int launch_schur_fk(psba_ctx *h, double mu);
+int launch_backsub_fk(psba_ctx *h, double mu);
 // kernels_pcg.hip
 int launch_bsr_finalize(psba_ctx *h, double mu);
 int launch_pcg_solve(psba_ctx *h);

@@ -102,6 +102,7 @@ void psba_tr_default_options(psba_tr_options *o) {
 
 int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result *res, double *log) {
   if (!h || !opts || !res) return PSBA_E_INVALID;
+  if (h->cnp != 6) return PSBA_E_STATE;  // free intrinsics: psba_levmar only (include/psba_hip.h)
   const double EPS2 = 1e-12, MAX_DELTA = 10000;  // psba.h:9, trust_region.cpp:18
   *res = psba_tr_result();
   auto t_begin = std::chrono::steady_clock::now();

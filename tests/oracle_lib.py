@@ -224,3 +224,48 @@ def levmar_all_cores(prob, max_iter=10, tr_handoff=False):
       log.ctypes.data_as(C.c_void_p))
     return res, int(lib.orc_threads())
 
+
+
+# ---- free intrinsics: the oracle's twin on 11-parameter camera blocks (parity unpinned) ----
+_fk_ex = _sig("orc_fk_exQT", None, _i, _dp, _dp, _dp, _dp, _ip, _ip, _dp)
+_fk_jac = _sig("orc_fk_jacobi", None, _i, _dp, _dp, _dp, _ip, _ip, _dp, _dp)
+_fk_normal = _sig("orc_fk_normal", _d, _i, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp)
+_fk_lm = _sig("orc_fk_levmar", _i, _i, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, C.POINTER(LmOpts), C.POINTER(LmResult), C.c_void_p)
+
+
+class OracleFreeK:
+    """Camera block (fu, u0, v0, ar, s | v | t): cams11[nC, 11] from the problem's K and cams."""
+
+    def __init__(self, prob):
+        self.nC, self.nP, self.nO = int(prob["nC"]), int(prob["nP"]), int(prob["nO"])
+        self.initrot = _c(prob["initrot"]).reshape(-1)
+        self.impts = _c(prob["impts"]).reshape(-1)
+        self.iidx, self.jidx = _c(prob["iidx"], np.int32), _c(prob["jidx"], np.int32)
+        self.cams = np.hstack([_c(prob["K"]).reshape(self.nC, 5), _c(prob["cams"]).reshape(self.nC, 6)]).reshape(-1).copy()
+        self.pts = _c(prob["pts"]).reshape(-1).copy()
+        self.nA, self.nT = 11 * self.nC, 11 * self.nC + 3 * self.nP
+
+    def exQT(self, cams=None, pts=None):
+        ex = np.empty(2 * self.nO)
+        _fk_ex(self.nO, self.impts, self.initrot, self.cams if cams is None else _c(cams).reshape(-1),
+               self.pts if pts is None else _c(pts).reshape(-1), self.iidx, self.jidx, ex)
+        return ex
+
+    def jacobi(self):
+        JA, JB = np.empty(22 * self.nO), np.empty(6 * self.nO)
+        _fk_jac(self.nO, self.initrot, self.cams, self.pts, self.iidx, self.jidx, JA, JB)
+        return JA.reshape(-1, 2, 11), JB.reshape(-1, 2, 3)
+
+    def normal(self):
+        """(||e||^2, J^T J dense, J^T e)"""
+        N, g = np.empty(self.nT * self.nT), np.empty(self.nT)
+        cost = _fk_normal(self.nC, self.nP, self.nO, self.impts, self.initrot, self.cams, self.pts, self.iidx, self.jidx, N, g)
+        return cost, N.reshape(self.nT, self.nT), g
+
+    def levmar(self, max_iter=20, log_cap=256, init_mu=0.0):
+        opts = LmOpts(max_iter, 0, 0, log_cap, 0, init_mu)
+        res = LmResult()
+        log = np.zeros((max(log_cap, 1), 5))
+        _fk_lm(self.nC, self.nP, self.nO, self.impts, self.initrot, self.cams, self.pts, self.iidx, self.jidx,
+               C.byref(opts), C.byref(res), log.ctypes.data_as(C.c_void_p))
+        return res, log[: res.n_log].copy()
