@@ -413,7 +413,7 @@ int psba_chol_dist_finish(psba_handle h);
 typedef struct psba_schur_plan *psba_schur_plan_t;
 psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
                                          const int *jidx);
-int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]);
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[7]); /* info[6] > 0: the runs layout (items as [turn][512] per workgroup, a thread's consecutive items grouped into runs of one position), number of runs */
 int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long long *wg,
                          int *blockpos, int *glo);
 void psba_schur_plan_destroy(psba_schur_plan_t p);

@@ -262,9 +262,9 @@ def schur_plan(n_cams, n_pts, iidx, jidx):
     if not p:
         raise PsbaError(-1, "psba_schur_plan_create failed")
     try:
-        info = (C.c_longlong * 6)()
+        info = (C.c_longlong * 7)()
         lib.psba_schur_plan_info(p, info)
-        groups, nwg, nslots, products, slab, nblocks = (int(x) for x in info)
+        groups, nwg, nslots, products, slab, nblocks, run_tasks = (int(x) for x in info)
         items = np.zeros(nslots, dtype=np.uint64)
         wg = np.zeros((nwg, 7), dtype=np.int64)
         blockpos = np.zeros(nblocks, dtype=np.int32)
@@ -274,7 +274,7 @@ def schur_plan(n_cams, n_pts, iidx, jidx):
     finally:
         lib.psba_schur_plan_destroy(p)
     return dict(groups=groups, items=items, wg=wg, blockpos=blockpos, glo=glo, products=products,
-                slab_doubles=slab)
+                slab_doubles=slab, run_tasks=run_tasks)
 
 
 def owner_plan(n_cams, n_pts, iidx, jidx, pattern=None):

@@ -304,6 +304,121 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   }
 }
 
+// The same assembly for items in the RUNS layout (schur_plan.cpp): [turn][RUN_THREADS], a thread's consecutive
+// items grouped into runs of one block position.  A run is summed in 36 registers and reaches the LDS once, at
+// its end -- on clustered tracks (neighbouring points sharing camera sets, i.e. real reconstructions) that is one
+// set of atomics per up to RUN_MAX products instead of one per product on ONE address.  512 threads: the 36
+// accumulators take the kernel to ~190 registers, two waves per SIMD.
+template <bool DUMP>
+__global__ __launch_bounds__(RUN_THREADS) void k_schur_lds_runs(SchurLdsArgs p) {
+  extern __shared__ double sPart[];  // [nblk][37]
+  const int tid = threadIdx.x;
+  int w = blockIdx.x;
+  if ((p.nWg & 7) == 0) w = (blockIdx.x & 7) * (p.nWg >> 3) + (blockIdx.x >> 3);
+  const SchurWg wg = p.wg[w];
+  for (int t = tid; t < BLK_STRIDE * wg.nblk; t += RUN_THREADS) sPart[t] = 0.0;
+  __syncthreads();
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) acc[k] = 0.0;
+  int cur = -1;
+  unsigned long long item_next = (wg.item0 + tid < wg.item1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
+  for (long long t = wg.item0 + tid; t < wg.item1; t += RUN_THREADS) {
+    const unsigned long long item = item_next;
+    if (t + RUN_THREADS < wg.item1) item_next = p.items[t + RUN_THREADS];
+    if (item == SCHUR_NULL_ITEM) continue;  // (only behind a thread's last item)
+    const int a = wg.obs0 + (int)(item & ((1u << ITEM_OBS_BITS) - 1));
+    const int i = wg.pt0 + (int)((item >> ITEM_OBS_BITS) & ((1u << ITEM_PT_BITS) - 1));
+    const int boff = (int)((item >> (ITEM_OBS_BITS + ITEM_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
+    const int pos = (int)(item >> (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
+    const double *pv = p.PV + 9 * (size_t)i;
+    const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
+    const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
+    double v[6], vi[6], wv[18], wb[18];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = pv[k];
+    const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const double2 q = wa[k];
+      wv[2 * k] = q.x;
+      wv[2 * k + 1] = q.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const double2 q = wb2[k];
+      wb[2 * k] = q.x;
+      wb[2 * k + 1] = q.y;
+    }
+    if (pos != cur) {  // the run of the previous block is over: its sums into the partition
+      if (cur >= 0) {
+        double *blk = sPart + BLK_STRIDE * cur;
+#pragma unroll
+        for (int k = 0; k < 36; k++) atomicAdd(&blk[k], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 36; k++) acc[k] = 0.0;
+      cur = pos;
+    }
+    v[0] += p.mu;
+    v[3] += p.mu;
+    v[5] += p.mu;
+    if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
+    if (DUMP) {
+      double *o = p.dbg_Vinv + 9 * (size_t)i;
+      o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
+      o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
+      o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
+    }
+    const bool self = boff == 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) vi[k] = -vi[k];  // Y carries the sign of the product
+    double Y[18], e[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double w0 = wv[3 * r], w1 = wv[3 * r + 1], w2 = wv[3 * r + 2];
+      Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+      Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+      Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+      e[r] = Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2;
+    }
+    if (DUMP && self) {
+#pragma unroll
+      for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = -Y[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double val = fma(Y[3 * r + 2], wb[3 * c + 2], fma(Y[3 * r + 1], wb[3 * c + 1], Y[3 * r] * wb[3 * c]));
+        // the self-product's e_a terms ride in redundant upper-triangle slots (EA_SLOT)
+        if (r == 0 && c >= 1) val = self ? e[c - 1] : val;
+        if (r == 1 && c == 2) val = self ? e[5] : val;
+        acc[6 * r + c] += val;
+      }
+  }
+  if (cur >= 0) {
+    double *blk = sPart + BLK_STRIDE * cur;
+#pragma unroll
+    for (int k = 0; k < 36; k++) atomicAdd(&blk[k], acc[k]);
+  }
+  __syncthreads();
+  double2 *slab = reinterpret_cast<double2 *>(p.slab + wg.slab_off);
+  for (int t = tid; t < 18 * wg.nblk; t += RUN_THREADS) {
+    const double *src = sPart + BLK_STRIDE * (t / 18) + 2 * (t % 18);
+    slab[t] = make_double2(src[0], src[1]);
+  }
+  if (p.diag0) {
+    for (int t = tid; t < 21 * 36; t += RUN_THREADS) {
+      const int b = t / 36, rc = t % 36;
+      if (p.diag_grp[b] == wg.group) {
+        const double v = sPart[BLK_STRIDE * p.diag_pos[b] + rc];
+        if (v != 0.0) atomicAdd(&p.diag0[t], v);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_schur_reduce(SchurReduceArgs p) {
   __shared__ double2 sAcc[8][32];
   __shared__ Factor32Lds sF;
@@ -650,8 +765,16 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
       const int mode = m ? atoi(m) : 0;
       const dim3 G(h->nWg), B(SCHUR_THREADS);
       bool launched = false;
+      if (h->schur_runs) {  // clustered tracks: items in the runs layout
+        const dim3 Br(RUN_THREADS);
+        if (dump)
+          hipLaunchKernelGGL((k_schur_lds_runs<true>), G, Br, lds, h->stream, a);
+        else
+          hipLaunchKernelGGL((k_schur_lds_runs<false>), G, Br, lds, h->stream, a);
+        launched = true;
+      }
 #ifdef PSBA_BUILD_EXPERIMENTS
-      if (!dump && mode > 0) launched = launch_schur_lds_mode(mode, G, B, lds, h->stream, a);  // kernels_schur_modes.hip
+      if (!launched && !dump && mode > 0) launched = launch_schur_lds_mode(mode, G, B, lds, h->stream, a);  // kernels_schur_modes.hip
 #endif
       (void)mode;
       if (launched) {
@@ -725,6 +848,8 @@ int launch_schur(psba_ctx *h, double mu, bool dump) {
       const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<true>, attr, dyn));
       PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds<false>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds_runs<true>, attr, dyn));
+      PSBA_HIP(h, hipFuncSetAttribute((const void *)k_schur_lds_runs<false>, attr, dyn));
       h->lds_attr_set = true;
     }
     return launch_schur_lds(h, mu, dump);

@@ -544,6 +544,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   } else if (!sparse && !h->ring_nWg) {
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
+    h->schur_runs = h->nGroups > 0 && plan.runs;
     if (h->nGroups) {
       TRY(dev_alloc(h, &h->items, plan.items.size() ? plan.items.size() : 1));
       TRY(dev_alloc(h, &h->wg, plan.wgs.size()));
@@ -575,8 +576,8 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
       PSBA_HIP(h, hipMemset(h->diag0, 0, sizeof(double) * 21 * 36));
       if (getenv("PSBA_SCHUR_PLAN_INFO"))
-        fprintf(stderr, "[psba] K2 plan: %d groups, %d workgroups, %lld products in %zu item slots (fill %.3f), slabs %.1f MB\n",
-                h->nGroups, h->nWg, plan.real_items, plan.items.size(),
+        fprintf(stderr, "[psba] K2 plan%s: %d groups, %d workgroups, %lld products in %zu item slots (fill %.3f), slabs %.1f MB\n",
+                plan.runs ? " (runs layout)" : "", h->nGroups, h->nWg, plan.real_items, plan.items.size(),
                 plan.items.size() ? (double)plan.real_items / (double)plan.items.size() : 1.0,
                 8e-6 * (double)plan.slab_doubles);
     } else {
@@ -1615,7 +1616,7 @@ psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, co
   return p;
 }
 
-int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]) {
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[7]) {
   if (!p || !info) return PSBA_E_INVALID;
   info[0] = p->ctx.nGroups;
   info[1] = p->ctx.nGroups ? p->ctx.nWg : 0;
@@ -1623,6 +1624,7 @@ int psba_schur_plan_info(psba_schur_plan_t p, long long info[6]) {
   info[3] = p->plan.real_items;
   info[4] = (long long)p->plan.slab_doubles;
   info[5] = p->nBlocks;
+  info[6] = p->plan.runs ? p->plan.tasks : 0;  // > 0: the runs layout ([turn][512] per workgroup), number of runs
   return PSBA_OK;
 }
 

@@ -131,7 +131,13 @@ struct SchurPlanHost {
   std::vector<int> posblock;   // inverse, groups concatenated: (j << 16) | k, -1 = padding
   size_t slab_doubles = 0;
   long long real_items = 0;
+  // runs layout (clustered tracks, see build_schur_plan): a workgroup's items as [turn][RUN_THREADS], every
+  // thread's consecutive items grouped into runs of one block position; tasks = number of such runs
+  bool runs = false;
+  long long tasks = 0;
 };
+constexpr int RUN_THREADS = 512;  // threads of a workgroup of k_schur_lds_runs (36 more accumulators per lane: 2 waves per SIMD)
+constexpr int RUN_MAX = 32;       // products a lane sums in registers before it touches the LDS at the latest
 }  // namespace psba
 
 struct psba_ctx {
@@ -229,6 +235,7 @@ struct psba_ctx {
 #endif
   // block-sparse S + preconditioned CG (psba_set_solver, kernels_pcg.hip)
   int solver = 0;               // PSBA_SOLVER_*
+  bool schur_runs = false;  // K2's items are in the runs layout (k_schur_lds_runs)
   int cnp = 6;  // parameters per camera: 6 (fixed intrinsics, the reference's kernels) or 11 (psba_set_camera_model: free intrinsics)
   double pcg_tol = 1e-10;
   int pcg_maxit = 500, pcg_iters = 0;

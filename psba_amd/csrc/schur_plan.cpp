@@ -19,6 +19,14 @@
 //    bank pair may be used a second time (never a third): one extra LDS pass for that row
 //    instead of a hole -- rows stay short-lived (3 open at a time), which keeps the items of a
 //    point, and with them the W rows a wave reads, together.  Remaining holes are null items.
+//  * RUNS layout (round 4): real reconstructions list their points so that neighbours share camera sets, and
+//    the same block of S then receives products from many consecutive points -- with the rows above those
+//    products sit in neighbouring lanes, hit ONE LDS address and are serialised (venice-shaped with runs of 16
+//    points per camera set: 78 us against 49 for the uniform draw; 64 points: 105).  When a block's products come
+//    in runs (mean run >= 2 over the plan), a workgroup's items are instead dealt as TASKS: the products of
+//    one block, in point order, cut into runs of at most RUN_MAX; tasks ordered by their first point and handed
+//    to the 512 threads round-robin; a thread sums a task in 36 registers and touches the LDS once per task.
+//    Neighbouring threads then work on different blocks of the SAME points, turn after turn.
 #include <algorithm>
 #include <cstdint>
 #include <numeric>
@@ -207,6 +215,25 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       raw[grp_of_blk[blk]].push_back({a, i, a - b, out.blockpos[blk]});
     }
   }
+  // runs of one block over consecutive products of a group's point-major list: how clustered are the tracks?
+  long long n_tasks_probe = 0;
+  for (int g = 0; g < G; g++) {
+    std::vector<int> last((size_t)h->gnblk[g], -2), len((size_t)h->gnblk[g], 0);
+    int prev_pt = -1, pt_ord = -1;
+    for (const Raw &it : raw[g]) {
+      if (it.i != prev_pt) {
+        prev_pt = it.i;
+        pt_ord++;
+      }
+      // a run continues when the block's previous product came from the previous point that touches this group
+      if (last[(size_t)it.pos] != pt_ord - 1 && last[(size_t)it.pos] != pt_ord) n_tasks_probe++, len[(size_t)it.pos] = 0;
+      if (++len[(size_t)it.pos] > RUN_MAX) n_tasks_probe++, len[(size_t)it.pos] = 1;
+      last[(size_t)it.pos] = pt_ord;
+    }
+  }
+  out.runs = n_tasks_probe > 0 && (double)total_items / (double)n_tasks_probe >= 2.0 && !block_ranges;
+  if (const char *e = getenv("PSBA_SCHUR_RUNS")) out.runs = atoi(e) != 0 && !block_ranges;
+  out.tasks = 0;
   struct WgTmp { SchurWg w; double where; };
   std::vector<WgTmp> wgs;
   out.items.clear();
@@ -224,8 +251,58 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
         h->nGroups = 0;  // the item encoding does not hold this range: owner route instead
         return PSBA_OK;
       }
-      // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
       const size_t base = out.items.size();
+      if (out.runs) {
+        // tasks: per block position the range's products in order, cut at RUN_MAX; ordered by first product
+        struct Task { size_t first; std::vector<size_t> idx; };
+        std::vector<Task> tasks;
+        // (a small range: shorter runs, so that every thread gets a few of them)
+        const size_t run_cap = std::min<size_t>((size_t)RUN_MAX, std::max<size_t>(2, (r1 - r0) / (2 * RUN_THREADS)));
+        {
+          std::vector<int> open((size_t)w.nblk, -1);
+          for (size_t t = r0; t < r1; t++) {
+            const int pos = raw[g][t].pos;
+            if (open[(size_t)pos] < 0 || tasks[(size_t)open[(size_t)pos]].idx.size() >= run_cap) {
+              open[(size_t)pos] = (int)tasks.size();
+              tasks.push_back({t, {}});
+            }
+            tasks[(size_t)open[(size_t)pos]].idx.push_back(t);
+          }
+        }
+        out.tasks += (long long)tasks.size();
+        // (already ordered by first product: a task is created when its first product is met)
+        // round-robin over the threads in task order: the tasks that begin at the same points (one per block of a
+        // run of points with one camera set) land in neighbouring threads and read the same W rows turn by turn
+        // (... but a thread that is ahead of the others is passed over: the lists stay within a run of each other)
+        std::vector<std::vector<unsigned long long>> list((size_t)RUN_THREADS);
+        size_t thr = RUN_THREADS - 1, level = 0, scanned = 0;
+        for (size_t q = 0; q < tasks.size(); q++) {
+          do {
+            thr = (thr + 1) % RUN_THREADS;
+            if (++scanned > (size_t)RUN_THREADS) {
+              level += 2;
+              scanned = 0;
+            }
+          } while (list[thr].size() > level);
+          scanned = 0;
+          for (size_t t : tasks[q].idx) {
+            const Raw &it = raw[g][t];
+            list[thr].push_back((unsigned long long)(it.a - w.obs0) | ((unsigned long long)(it.i - w.pt0) << ITEM_OBS_BITS) |
+                                ((unsigned long long)it.boff << (ITEM_OBS_BITS + ITEM_PT_BITS)) |
+                                ((unsigned long long)it.pos << (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS)));
+          }
+        }
+        size_t T = 0;
+        for (const auto &l : list) T = l.size() > T ? l.size() : T;
+        out.items.resize(base + T * RUN_THREADS, SCHUR_NULL_ITEM);
+        for (int thr = 0; thr < RUN_THREADS; thr++)
+          for (size_t t = 0; t < list[(size_t)thr].size(); t++) out.items[base + t * RUN_THREADS + thr] = list[(size_t)thr][t];
+        w.item0 = (long long)base;
+        w.item1 = (long long)out.items.size();
+        wgs.push_back({w, n ? (double)(r0 + r1) / (2.0 * (double)n) : 0.0});
+        continue;
+      }
+      // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
       size_t closed = 0;  // rows [0, closed) are final
       std::vector<uint16_t> mask, mask2;  // bank pairs used once / twice in a row
       std::vector<int> fill;

@@ -138,7 +138,7 @@ def _rotmat(q):
 
 
 def shaped_from_cams(cams_file, n_pts, mean_track, seed, shard=0, min_track=2, noise_px=1.0,
-                     cam_sigma=1e-3, pt_sigma=1e-2):
+                     cam_sigma=1e-3, pt_sigma=1e-2, cluster=1):
     """SURVEY 8(d)'s stand-in for a dataset whose point file is missing: the REAL cameras of a
     12-column sba cams file (K5, unit quaternion, t; data/*-cams.txt), the named number of points,
     track length k ~ min_track + Geometric with the named mean (capped at the camera count), k
@@ -146,7 +146,10 @@ def shaped_from_cams(cams_file, n_pts, mean_track, seed, shard=0, min_track=2, n
     pushed along their mean optical axis until it has positive depth in all k views, observation
     = the reference's projection of the true point + N(0, 1 px), initial parameters = truth +
     a small perturbation.  Cameras (and their perturbation) depend on `seed` only, points and
-    observations also on `shard` (shards of one seed = pieces of one larger problem)."""
+    observations also on `shard` (shards of one seed = pieces of one larger problem).
+    `cluster` > 1: runs of that many consecutive points share ONE camera set (track length and cameras drawn once
+    per run) -- what real reconstructions look like in file order, where neighbouring points come from the same
+    image pairs; SURVEY 8(d)'s uniform draw (cluster = 1) is the worst case for block locality in S."""
     a = np.loadtxt(cams_file, comments="#", ndmin=2)
     if a.shape[1] != 12:
         raise ValueError(f"{cams_file}: expected 12 columns (K5 q4 t3), got {a.shape[1]}")
@@ -161,15 +164,22 @@ def shaped_from_cams(cams_file, n_pts, mean_track, seed, shard=0, min_track=2, n
     rng = np.random.default_rng([seed, 1 + shard])
     rng_cam = np.random.default_rng([seed, 0])
     extra = max(mean_track - min_track, 1e-9)
-    k = min_track + rng.geometric(1.0 / (1.0 + extra), size=n_pts) - 1
-    k = np.clip(k, min_track, n_cams)
+    n_runs = (n_pts + cluster - 1) // cluster
+    k_run = min_track + rng.geometric(1.0 / (1.0 + extra), size=n_runs) - 1
+    k_run = np.clip(k_run, min_track, n_cams)
+    run_of = np.arange(n_pts) // cluster
+    k = k_run[run_of]
     iidx = np.repeat(np.arange(n_pts, dtype=np.int32), k)
     jidx = np.empty(iidx.size, dtype=np.int32)
     off = np.concatenate([[0], np.cumsum(k)])
-    for kk in np.unique(k):
+    for kk in np.unique(k_run):
+        runs = np.nonzero(k_run == kk)[0]
+        keys = rng.random((runs.size, n_cams))
+        pick_run = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
+        where = np.full(n_runs, -1)
+        where[runs] = np.arange(runs.size)
         rows = np.nonzero(k == kk)[0]
-        keys = rng.random((rows.size, n_cams))
-        pick = np.sort(np.argpartition(keys, kk - 1, axis=1)[:, :kk], axis=1).astype(np.int32)
+        pick = pick_run[where[run_of[rows]]]
         dest = (off[rows][:, None] + np.arange(kk)[None, :]).reshape(-1)
         jidx[dest] = pick.reshape(-1)
     spread = float(np.linalg.norm(C.std(axis=0)))
@@ -233,10 +243,10 @@ def shaped_from_cams(cams_file, n_pts, mean_track, seed, shard=0, min_track=2, n
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data")
 
 
-def venice_shaped(n_pts=64053, seed=0x5BA0 + 4, shard=0):
+def venice_shaped(n_pts=64053, seed=0x5BA0 + 4, shard=0, cluster=1):
     """Venice-52-64053-shaped (BASELINE configs[3]): the 52 real cameras of
-    data/Venice-52-64053-cams.txt, 64053 synthetic points, mean track 5.42."""
-    return shaped_from_cams(os.path.join(_DATA, "Venice-52-64053-cams.txt"), n_pts, 5.42, seed, shard=shard)
+    data/Venice-52-64053-cams.txt, 64053 synthetic points, mean track 5.42.  cluster: see shaped_from_cams."""
+    return shaped_from_cams(os.path.join(_DATA, "Venice-52-64053-cams.txt"), n_pts, 5.42, seed, shard=shard, cluster=cluster)
 
 
 def trafalgar50_shaped(seed=0x5BA0 + 3, shard=0):

@@ -1039,3 +1039,43 @@ def test_tail_kernel_experiment(tail, monkeypatch):
             h.close()
         assert np.abs(outs[1][0] - outs[0][0]).max() <= 1e-10 * np.abs(outs[0][0]).max()
         assert abs(outs[1][1] - outs[0][1]) <= 1e-12 * outs[0][1]
+
+
+@pytest.mark.parametrize("cluster,force", [(8, None), (1, "1"), (8, "0")])
+def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
+    """K2's runs layout (k_schur_lds_runs; round 4): on clustered tracks a thread sums a run of one block's products
+    in registers and touches the LDS once per run.  S, e_a, dpa and the try's scalars against the ORACLE on a
+    clustered venice-shaped problem (layout chosen by the plan), on the uniform draw with the layout forced
+    (PSBA_SCHUR_RUNS=1: runs of length ~1, every code path of the kernel), and on the clustered problem with the
+    row layout forced (PSBA_SCHUR_RUNS=0)."""
+    import psba_amd
+    import psba_amd.synth as synth
+    if force is not None:
+        monkeypatch.setenv("PSBA_SCHUR_RUNS", force)
+    prob = synth.venice_shaped(n_pts=12000, cluster=cluster)
+    o = Oracle(prob)
+    lin = o.linearize()
+    mu = 1e-3 * lin["maxdiag"]
+    sch = o.schur(lin, mu)
+    st, odp, _ = o.solve(lin, sch)
+    assert st == 0.0
+    h = psba_amd.Psba(0)
+    h.upload_problem(prob)
+    assert h.schur_path() == 0
+    plan = psba_amd.capi.schur_plan(prob["nC"], prob["nP"], prob["iidx"], prob["jidx"])
+    assert (plan["run_tasks"] > 0) == (force == "1" or (force is None and cluster > 1))
+    h.linearize(1.0, 1.0)
+    h.schur_assemble(mu)
+    nA = o.nA
+    n32 = (nA + 31) // 32 * 32
+    M = h.get_reduce_buffer().reshape(n32 + 1, n32)
+    close(M[:nA, :nA], sch["S"], 1e-11, "S")
+    close(M[n32, :nA], sch["eab"][:nA], 1e-10, "ea")
+    h.schur_reduce()
+    h.schur_solve()
+    sc = h.backsub(mu)
+    assert sc.status == 0
+    close(h.get_dp()[:nA], odp[:nA], 1e-8, "dpa")
+    # the mirror verbs dump Y and V^-1 through the same kernel
+    close(h.compute_Yblks(), sch["Y"], 1e-10, "Y")
+    h.close()

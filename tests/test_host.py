@@ -102,6 +102,8 @@ def _check_plan(nC, nP, iidx, jidx):
         assert len(nblk) == 1 and ps.max() < nblk.pop() <= (b1 - b0 + 15) // 16 * 16
     seen = set()
     slabs = set()
+    runs = plan["run_tasks"] > 0
+    n_runs = 0
     for w in wg:
         g, nblk, obs0, pt0, s0, s1, slab = (int(x) for x in w)
         assert s0 % 16 == 0 and s1 % 16 == 0 and (g, slab) not in slabs
@@ -112,9 +114,25 @@ def _check_plan(nC, nP, iidx, jidx):
         i = pt0 + ((it >> np.uint64(24)) & np.uint64(0x3FFFFF)).astype(np.int64)  # 22 bits
         boff = ((it >> np.uint64(46)) & np.uint64(0xFF)).astype(np.int64)
         p = ((it >> np.uint64(54)) & np.uint64(0x3FF)).astype(np.int64)
-        for r in range(0, len(it), 16):
-            q = np.unique(p[r:r + 16][live[r:r + 16]]) % 16  # lanes on one address serialise wherever they sit
-            assert np.bincount(q, minlength=16).max() <= 2  # a bank pair: at most two addresses per row
+        if runs:
+            # the runs layout: [turn][512]; a thread's live items come first, grouped into runs of one position of
+            # at most 32 products, each run in point order, and a position never comes back in a later run of the
+            # same thread sooner than ... (it may: a block with more than 32 products has several runs)
+            assert (s1 - s0) % 512 == 0
+            T = (s1 - s0) // 512
+            L, P, I = live.reshape(T, 512), p.reshape(T, 512), i.reshape(T, 512)
+            assert not (L[1:] & ~L[:-1]).any()          # no live item behind a null one
+            for thr in range(512):
+                n = int(L[:, thr].sum())
+                pp, ii = P[:n, thr], I[:n, thr]
+                cut = np.flatnonzero(np.diff(pp) != 0) + 1
+                for seg in np.split(np.arange(n), cut):
+                    assert len(seg) <= 32 and (np.diff(ii[seg]) >= 0).all()
+                n_runs += len(cut) + (1 if n else 0)
+        else:
+            for r in range(0, len(it), 16):
+                q = np.unique(p[r:r + 16][live[r:r + 16]]) % 16  # lanes on one address serialise wherever they sit
+                assert np.bincount(q, minlength=16).max() <= 2  # a bank pair: at most two addresses per row
         a, i, boff, p = a[live], i[live], boff[live], p[live]
         b = a - boff
         assert (iidx[a] == i).all() and (iidx[b] == i).all() and (b >= ptr[i]).all()
@@ -127,6 +145,8 @@ def _check_plan(nC, nP, iidx, jidx):
         seen |= keys
     want = int(((np.arange(len(iidx)) - ptr[iidx]) + 1).sum())
     assert len(seen) == want == plan["products"]
+    if runs:  # (two runs of one position that meet in a thread's list merge: never more runs than the plan says)
+        assert 0 < n_runs <= plan["run_tasks"]
     # balance: item counts of the workgroups of one group differ by at most one
     for g in range(plan["groups"]):
         n = [int(((items[int(w[4]):int(w[5])]) != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()) for w in wg if w[0] == g]
@@ -144,9 +164,23 @@ def test_schur_plan_venice_shaped():
     from psba_amd import synth
     pr = synth.venice_shaped()
     plan = _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+    assert plan["run_tasks"] == 0  # the uniform draw of SURVEY 8(d) has no runs: the row layout
     # the bank-pair schedule should cost little padding on a realistic problem
     assert plan["products"] / len(plan["items"]) > 0.75
     assert len(plan["wg"]) == 256
+
+
+@pytest.mark.parametrize("cluster", [4, 16])
+def test_schur_plan_clustered_tracks_take_the_runs_layout(cluster):
+    """Neighbouring points that share camera sets (what real reconstructions look like in file order): a block's
+    products come in runs, and the plan hands every thread whole runs (summed in registers, one set of LDS atomics
+    per run) instead of dealing single products into bank-pair rows."""
+    from psba_amd import synth
+    pr = synth.venice_shaped(cluster=cluster)
+    plan = _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+    assert plan["run_tasks"] > 0
+    assert plan["products"] / plan["run_tasks"] >= 0.5 * min(cluster, 6)   # runs about as long as the clusters (capped per workgroup: 6200 products, 512 threads)
+    assert plan["products"] / len(plan["items"]) > 0.75                     # [turn][512] padding
 
 
 @pytest.mark.parametrize("n_cams", [300, 700])
