@@ -179,6 +179,47 @@ def load_workload(name, rank, nranks, strong, cfg5_points):
     return (capi.shard_problem(full, nranks, rank) if nranks > 1 else full), "reference data/*.txt"
 
 
+def clustered_extra(device, cluster=16):
+    """the same 52 cameras and point count with CLUSTERED tracks (runs of `cluster` consecutive
+    points sharing one camera set: what real reconstructions look like in file order; the headline's uniform draw is
+    the worst case for block locality in S).  The graded pair (one HIP-event span over the assembly + reduce kernels)
+    and a short LM run; an extra key, never the headline."""
+    prob = synth.venice_shaped(cluster=cluster)
+    h = psba_amd.Psba(device)
+    h.upload_problem(prob)
+    plan_runs = capi.schur_plan(prob["nC"], prob["nP"], prob["iidx"], prob["jidx"])["run_tasks"]
+    h.linearize(1.0, 1.0)
+    mu = 1e-3 * h.max_diag()
+    h.profile_enable(1 << capi.K_SCHUR)
+    for _ in range(5):
+        h.schur_assemble(mu)
+    h.profile_reset()
+    for _ in range(30):
+        h.schur_assemble(mu)
+    ms, n = h.profile_get(capi.K_SCHUR)
+    pair_us = 1e3 * ms / max(n, 1)
+    b = h.algorithmic_bytes(capi.K_SCHUR)
+    h.profile_enable(0)
+
+    def seg():
+        h.reset_params()
+        t = time.perf_counter()
+        r, _ = h.levmar(max_iter=10, tr_handoff=False, log_cap=0)
+        return r, time.perf_counter() - t
+    for _ in range(5):
+        seg()
+    done, dt = 0, 0.0
+    for _ in range(3):
+        r, d_ = seg()
+        done += r.iters
+        dt += d_
+    h.close()
+    return {"tracks": f"runs of {cluster} consecutive points share one camera set", "n_obs": int(prob["nO"]),
+            "schur_layout": "runs (a thread sums a run of one block's products in registers)" if plan_runs else "rows of 16 bank pairs",
+            "pair_us": pair_us, "roofline_frac": b / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "ms_per_lm_iter": 1e3 * dt / max(done, 1), "M_obs_per_s": prob["nO"] * done / dt / 1e6}
+
+
 def cfg5_extra(device):
     """BASELINE configs[4] at FULL size on one GPU (synth.cfg5(): 2000 cameras x 2 M points x 20 M
     observations, dense 12 000 x 12 000 S), as an extra key of the default bench line: ms per LM
@@ -561,6 +602,11 @@ def main():
             out.update(extras)
     if rank == 0:
         # the full-size cfg5 in the driver's view (an extra key, never the headline value)
+        if world == 1 and args.workload == "venice-shaped" and not os.environ.get("PSBA_BENCH_NO_CLUSTERED"):
+            try:
+                out["clustered_tracks"] = clustered_extra(local_rank)
+            except Exception as e:
+                out["clustered_tracks"] = {"error": repr(e)}
         if world == 1 and args.workload == "venice-shaped" and not os.environ.get("PSBA_BENCH_NO_CFG5"):
             try:
                 out["cfg5_full_size"] = cfg5_extra(local_rank)

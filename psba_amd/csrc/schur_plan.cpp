@@ -23,7 +23,7 @@
 //    the same block of S then receives products from many consecutive points -- with the rows above those
 //    products sit in neighbouring lanes, hit ONE LDS address and are serialised (venice-shaped with runs of 16
 //    points per camera set: 78 us against 49 for the uniform draw; 64 points: 105).  When a block's products come
-//    in runs (mean run >= 2 over the plan), a workgroup's items are instead dealt as TASKS: the products of
+//    in runs (mean run >= 6 over the plan), a workgroup's items are instead dealt as TASKS: the products of
 //    one block, in point order, cut into runs of at most RUN_MAX; tasks ordered by their first point and handed
 //    to the 512 threads round-robin; a thread sums a task in 36 registers and touches the LDS once per task.
 //    Neighbouring threads then work on different blocks of the SAME points, turn after turn.
@@ -231,7 +231,9 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
       last[(size_t)it.pos] = pt_ord;
     }
   }
-  out.runs = n_tasks_probe > 0 && (double)total_items / (double)n_tasks_probe >= 2.0 && !block_ranges;
+  // (venice-shaped, assembly + reduce, rows / runs layout: runs of 4 points 59 / 68 us, 16: 78 / 59, 64: 105 / 57; the
+  // uniform draw 49 / 74 -- the runs kernel runs two waves per SIMD, so it only pays once runs are long)
+  out.runs = n_tasks_probe > 0 && (double)total_items / (double)n_tasks_probe >= 6.0 && !block_ranges;
   if (const char *e = getenv("PSBA_SCHUR_RUNS")) out.runs = atoi(e) != 0 && !block_ranges;
   out.tasks = 0;
   struct WgTmp { SchurWg w; double where; };

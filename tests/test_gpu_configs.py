@@ -1041,7 +1041,7 @@ def test_tail_kernel_experiment(tail, monkeypatch):
         assert abs(outs[1][1] - outs[0][1]) <= 1e-12 * outs[0][1]
 
 
-@pytest.mark.parametrize("cluster,force", [(8, None), (1, "1"), (8, "0")])
+@pytest.mark.parametrize("cluster,force", [(16, None), (1, "1"), (16, "0")])
 def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
     """K2's runs layout (k_schur_lds_runs; round 4): on clustered tracks a thread sums a run of one block's products
     in registers and touches the LDS once per run.  S, e_a, dpa and the try's scalars against the ORACLE on a
@@ -1077,5 +1077,10 @@ def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
     assert sc.status == 0
     close(h.get_dp()[:nA], odp[:nA], 1e-8, "dpa")
     # the mirror verbs dump Y and V^-1 through the same kernel
+    h.linearize(1.0, 1.0)
+    h.update_UV(mu)
+    rc, Vinv = h.compute_Vinv()
+    assert rc == 0
+    close(Vinv, sch["Vinv"], 1e-10, "Vinv")
     close(h.compute_Yblks(), sch["Y"], 1e-10, "Y")
     h.close()
