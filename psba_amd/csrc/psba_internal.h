@@ -136,7 +136,7 @@ struct SchurPlanHost {
   bool runs = false;
   long long tasks = 0;
 };
-constexpr int RUN_THREADS = 512;  // threads of a workgroup of k_schur_lds_runs (36 more accumulators per lane: 2 waves per SIMD)
+constexpr int RUN_THREADS = 512;  // threads of a workgroup of k_schur_lds_runs: 192 VGPRs with the 36 accumulators, two waves per SIMD (768 threads = 168 VGPRs spill 27 registers: 85 against 59 us)
 constexpr int RUN_MAX = 32;       // products a lane sums in registers before it touches the LDS at the latest
 }  // namespace psba
 
