@@ -307,9 +307,10 @@ class Ranks:
     def handle(self, prob):
         """One handle on this rank's GPU with the problem uploaded, inside a fresh communicator if N > 1."""
         h = psba_amd.Psba(self.local_rank)  # one process per GPU (RCCL refuses two ranks on one device)
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("PSBA_BENCH_REHEARSE"):
             uid = [psba_amd.Psba.comm_unique_id() if self.rank == 0 else None]
-            self.dist.broadcast_object_list(uid, src=0)
+            if self.dist is not None:
+                self.dist.broadcast_object_list(uid, src=0)
             # RCCL prints a version banner on stdout at communicator creation; stdout carries exactly
             # one JSON line, so the banner goes to stderr
             sys.stdout.flush()
@@ -514,7 +515,7 @@ def main():
                          "algorithmic_bytes_per_launch": sch_bytes, "avg_launch_us": sch_us,
                          "traffic": None},
         }
-        if world > 1:
+        if world > 1 or os.environ.get("PSBA_BENCH_REHEARSE"):
             out["multi_gpu"] = {"hardware_note": "first N > 1 measurements come from the driver's node: the builder has one GPU",
                                 "dense_factorization": "wide update sharded by 64-column block" if chol_sharded else "replicated",
                                 "bytes_per_try_per_rank": collective_bytes(int(prob["nC"]), world, chol_sharded)}
@@ -586,8 +587,11 @@ def main():
                     "final_cost": pres.final_err,
                 }
     h.close()
-    # N > 1, default workload: the other two multi-GPU configurations as extra keys (every rank takes part)
-    if world > 1 and args.workload == "venice-shaped" and not args.no_extras:
+    # N > 1, default workload: the other two multi-GPU configurations as extra keys (every rank takes part).
+    # (PSBA_BENCH_REHEARSE=1: the same code path on ONE GPU -- a one-rank RCCL communicator, the extras included --
+    # which is all of the multi-GPU flow a single-GPU box can rehearse)
+    rehearse = bool(os.environ.get("PSBA_BENCH_REHEARSE"))
+    if (world > 1 or rehearse) and args.workload == "venice-shaped" and not args.no_extras:
         extras = {}
         for key, (wl, st, steps, warm) in {("weak_scaling" if strong else "strong_scaling"):
                                            ("venice-shaped", not strong, args.steps, args.warmup),

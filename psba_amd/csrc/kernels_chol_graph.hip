@@ -205,13 +205,15 @@ __device__ __forceinline__ d4 update_tile(const double *Lw, const double *Lx, in
 }
 
 // workgroup 0's tail: factor the next diagonal block (in s.D) and store factor + inverse
+// store_L = false: the fused chain with identity rows -- nobody ever reads the diagonal block of the factor there
+// (the panels and the solve work with its inverse), so its 1024 stores stay off workgroup 0's path
 __device__ __forceinline__ void factor_next_block(Factor32Lds &s, double *Lx, int ld, int jn, double *linv,
-                                            int *status, int tid) {
+                                            int *status, int tid, bool store_L = true) {
   factor32(s, tid);
   double *lio = linv + (size_t)(jn / GB) * GB * GB;
   for (int t = tid; t < GB * GB; t += 256) {
     const int r = t / GB, c = t % GB;
-    Lx[(size_t)(jn + r) * ld + jn + c] = f32_L(s, r, c);
+    if (store_L) Lx[(size_t)(jn + r) * ld + jn + c] = f32_L(s, r, c);
     lio[t] = f32_Linv(s, r, c);
   }
   if (tid == 0 && s.fail) status[1] = status[3];
@@ -558,7 +560,8 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         sX[0][xr][lk + 4 * r][16 * half + li] = x[r];
-        Lx[(size_t)(16 * (T0 + xr) + lk + 4 * r) * ld + j + 16 * half + li] = x[r];
+        // (with the identity rows riding along only the e_a row's and their X are ever read back: k_cholg_solve)
+        if (nId == 0) Lx[(size_t)(16 * (T0 + xr) + lk + 4 * r) * ld + j + 16 * half + li] = x[r];
       }
     }
     __syncthreads();
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
     }
     if (!factor_next) return;  // (uniform)
     __syncthreads();
-    factor_next_block(s, Lx, ld, j + GB, linv, status, tid);
+    factor_next_block(s, Lx, ld, j + GB, linv, status, tid, nId == 0);
     return;
   }
   int TR, TC;
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
   if (!fresh) c = load_c_tile(Lw, ld, TR, TC, li, lk);  // in flight during the trsm
   d4 xl, xr;
   trsm_tile(Lw, ld, j, TR, nT, Li, li, lk, xl, xr);
-  if (TC == T0) store_x_tile(Lx, ld, j, TR, li, lk, xl, xr);
+  if (TC == T0 && (nId == 0 || TR >= nT - 1)) store_x_tile(Lx, ld, j, TR, li, lk, xl, xr);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     sX[wave][0][lk + 4 * r][li] = xl[r];
