@@ -618,6 +618,71 @@ __global__ __launch_bounds__(256) void k_cholg_panel(double *Lw, double *Lx, int
   store_c_tile(Lw, ld, TR, TC, li, lk, update_mfma(c, a, b));
 }
 
+// ---- the rows below a super-panel, once (round 4) ---------------------------------------------------------
+// Inside a super-panel the 32-column steps used to work on ALL rows below: every step read and wrote the
+// super-panel's remaining columns of the whole trailing matrix (~37 MB per step at n = 12 000: 13.8 GB per
+// factorization, the in-super-panel steps were HBM traffic, not latency -- profiles/r04_cfg5).  Now the
+// steps factor only the super-panel's own NB x NB diagonal block, and this kernel does the rest in one pass: one
+// wave per 16-row tile row below, X = C L_D^-T by block forward substitution over the nb = NB / 32 column blocks,
+//     X_k = (C_k - sum_{k' < k} X_k' L_kk'^T) L_kk^-T,
+// all of it wave-local (the finished pieces stay in registers as MFMA operands; L_D is 1.2 MB, cache-resident),
+// C read once, X written once.  Same flops as before, a sixth of the traffic, one launch instead of nb.
+// NBK = NB / 32 column blocks (a template parameter: the pieces live in registers, every index a constant)
+template <int NBK>
+__global__ __launch_bounds__(256) void k_cholg_trsm_block(const double *Lw, double *Lx, int ld, int J, int T_first,
+                                                          int nTall, const double *linv) {
+  __shared__ double sX[4][16][XS];  // a wave's scratch: accumulator layout -> operand layout
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int T = T_first + blockIdx.x * 4 + wave;
+  if (T >= nTall) return;
+  Row8 X[NBK];  // the finished pieces as A operands (row li, columns 8 lk .. 8 lk + 7 of the piece)
+#pragma unroll
+  for (int k = 0; k < NBK; k++) {
+    const int j = J + GB * k;
+    // the piece of C, in the accumulator layout (two 16x16 halves)
+    d4 cl, cr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      cl[r] = Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li];
+      cr[r] = Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 + li];
+    }
+    // minus the finished pieces times the blocks of L_D to the left of the diagonal
+#pragma unroll
+    for (int k2 = 0; k2 < k; k2++) {
+      const double *Lkk = Lx + (size_t)j * ld + J + GB * k2;  // L_D block (k, k2): rows j .., columns J + 32 k2 ..
+      const Row8 b0 = load_row8(Lkk + (size_t)li * ld + 8 * lk), b1 = load_row8(Lkk + (size_t)(16 + li) * ld + 8 * lk);
+      cl = update_mfma(cl, X[k2], b0);
+      cr = update_mfma(cr, X[k2], b1);
+    }
+    // through the scratch into the operand layout, times L_kk^-T
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sX[wave][lk + 4 * r][li] = cl[r];
+      sX[wave][lk + 4 * r][16 + li] = cr[r];
+    }
+    const Row8 a = load_row8(&sX[wave][li][8 * lk]);
+    const double *Li = linv + (size_t)(j / GB) * GB * GB;
+    const Row8 p = load_row8(Li + (size_t)li * GB + 8 * lk), q = load_row8(Li + (size_t)(16 + li) * GB + 8 * lk);
+    d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t], p.v[t], x0, 0, 0, 0);
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t], q.v[t], y0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t + 1], p.v[t + 1], x1, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t + 1], q.v[t + 1], y1, 0, 0, 0);
+    }
+    const d4 xl = x0 + x1, xr = y0 + y1;
+    store_x_tile(Lx, ld, j, T, li, lk, xl, xr);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sX[wave][lk + 4 * r][li] = xl[r];
+      sX[wave][lk + 4 * r][16 + li] = xr[r];
+    }
+    X[k] = load_row8(&sX[wave][li][8 * lk]);
+  }
+}
+
 // backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 32:
 // x_J = L_dd^-T y_J is a 32x32 mat-vec with the stored inverse (no dependent chain), then all
 // threads apply y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update do not depend on x
@@ -1156,22 +1221,42 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
   double *Lw = h->red, *Lx = h->chol_L, *linv = h->chol_ws;
   const int NB = c.NB;
   const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
+  // round 4: the steps factor the super-panel's own diagonal block only (tile rows < JE / 16), the rows below take
+  // ONE block triangular solve (k_cholg_trsm_block).  PSBA_CHOL_STEPS_ALL_ROWS=1: every step on all rows, as before.
+  // Pays from ~8000 columns on (n = 12 000: 16.91 -> 16.53 ms per factorization); below, the steps are single fused
+  // launches of a few microseconds and the block solve's serial chain of MFMAs per tile row is the longer way
+  // (per factorization, all rows / diagonal only: n = 2040 835 / 1038 us, 2400 1027 / 1282, 3600 1794 / 2088,
+  // 6000 4276 / 4506).  PSBA_CHOL_STEPS_DIAG_ONLY=1 forces it (tests).
+  const bool steps_all_rows = getenv("PSBA_CHOL_STEPS_ALL_ROWS") != nullptr;
+  const bool steps_diag_forced = getenv("PSBA_CHOL_STEPS_DIAG_ONLY") != nullptr;
+  const int nbk = (JE - J) / GB;
+  const bool diag_only = !steps_all_rows && (n32 >= 8192 || steps_diag_forced) && JE < n32 &&
+                         (nbk == 4 || nbk == 8 || nbk == 12 || nbk == 16);
+  const int nTs = diag_only ? JE / 16 : nT;  // tile rows the steps see
   for (int j = J; j < JE; j += GB) {
     const int T0 = (j + GB) / 16, TE = JE / 16;
-    long long tiles = 0;  // tiles of the super-panel's remaining columns, all rows below
-    for (int TC = T0; TC < TE; TC++) tiles += nT - TC;
+    if (diag_only && j + GB >= JE) break;  // nothing of the diagonal block is left below its last 32 columns
+    long long tiles = 0;  // tiles of the super-panel's remaining columns, all rows the steps see
+    for (int TC = T0; TC < TE; TC++) tiles += nTs - TC;
     if (j + GB < JE && tiles <= c.cols_fused_max) {
       // trsm + update in one kernel (every wave forms the X pieces of its tile itself: 40 MFMAs
       // per tile instead of 8, which pays while the step has few tiles -- per LM iteration
       // n = 3600: 2.17 against 2.36 ms, 6000: 4.72 / 4.78, 12 000 (all steps): 19.0 / 17.9)
-      hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nT, 0,
+      hipLaunchKernelGGL(k_cholg_panel, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j, nTs, 0,
                          TE, linv, h->status, 1);
       continue;
     }
-    hipLaunchKernelGGL(k_cholg_trsm, dim3((nT - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nT, nT, linv);
+    hipLaunchKernelGGL(k_cholg_trsm, dim3((nTs - T0 + 3) / 4), dim3(256), 0, s, Lw, Lx, ld, j, nTs, nTs, linv);
     if (j + GB < JE)
       hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
-                         nT, TE, linv, h->status);
+                         nTs, TE, linv, h->status);
+  }
+  if (diag_only) {  // the rows below the super-panel (and the e_a row): X = C L_D^-T in one pass
+    const dim3 g((nT - JE / 16 + 3) / 4), b(256);
+    if (nbk == 4) hipLaunchKernelGGL(k_cholg_trsm_block<4>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 8) hipLaunchKernelGGL(k_cholg_trsm_block<8>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 12) hipLaunchKernelGGL(k_cholg_trsm_block<12>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 16) hipLaunchKernelGGL(k_cholg_trsm_block<16>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
   }
   if (JE < n32) {
     const int Tw = JE / 16;

@@ -811,6 +811,8 @@ def test_two_level_blocked_panel_chain(monkeypatch, n_cams, lookahead):
     import psba_amd.synth as synth
     monkeypatch.setenv("PSBA_CHOL_BLOCKED", "1")
     monkeypatch.setenv("PSBA_CHOL_LOOKAHEAD", "1" if lookahead else "0")
+    if lookahead:  # ... and round 4's steps on the super-panel's diagonal block only + one block triangular solve
+        monkeypatch.setenv("PSBA_CHOL_STEPS_DIAG_ONLY", "1")  # for the rows below (default from n32 = 8192)
     monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")  # (the two-level chain is a form of the unfused one: blocked = !fused && ...)
     prob = synth.make_problem(n_cams=n_cams, n_pts=3000, mean_track=5.0, seed=300 + n_cams)
     o = Oracle(prob)
