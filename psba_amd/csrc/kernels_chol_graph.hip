@@ -1359,7 +1359,15 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   bool look = blocked && n32 >= 6000 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
   if (const char *e = getenv("PSBA_CHOL_LOOKAHEAD")) look = blocked && atoi(e) != 0 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
   if (look) {
-    if (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) look = false;
+    if (!h->chol_side) {
+      // the side stream at the LOWEST priority: the next super-panel's small dependent launches on the main stream
+      // must get a CU the moment one of the far update's workgroups retires -- at equal priority they waited ~60 us
+      // each for a slot (kernel trace) and the main stream, not the far update, set the pace
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&h->chol_side, hipStreamNonBlocking, getenv("PSBA_CHOL_SIDE_PRIO_DEFAULT") ? 0 : least) != hipSuccess)
+        look = false;
+    }
     const size_t need = 2 * (size_t)(n32 / c.NB + 2);
     while (look && h->chol_events.size() < need) {
       hipEvent_t e;
@@ -1379,7 +1387,7 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
         continue;
       }
       const bool has_update = J + c.NB < n32;
-      enqueue_superpanel(h, s, c, J, 0, 0, true, h->stream2, h->chol_events[2 * k], far_prev, h->chol_events[2 * k + 1]);
+      enqueue_superpanel(h, s, c, J, 0, 0, true, h->chol_side, h->chol_events[2 * k], far_prev, h->chol_events[2 * k + 1]);
       if (has_update) far_prev = h->chol_events[2 * k + 1];
     }
     if (far_prev) (void)hipStreamWaitEvent(s, far_prev, 0);  // the backward solve (and whoever comes next) behind the last far update

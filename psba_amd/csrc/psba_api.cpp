@@ -187,6 +187,16 @@ const char *psba_version(void) { return "psba_hip 0.1 (gfx950, fp64)"; }
 
 const char *psba_last_error(psba_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+// the handle's stream at the HIGHEST priority: the library's only concurrent work is the far updates of the blocked
+// Cholesky chain (lowest priority, kernels_chol_graph.hip), and the main stream's small dependent launches must win a
+// freed CU against them (PSBA_STREAM_PRIO_DEFAULT=1: default priority)
+static hipError_t create_main_stream(hipStream_t *s) {
+  int least = 0, greatest = 0;
+  if (getenv("PSBA_STREAM_PRIO_DEFAULT") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 int psba_create(int device, psba_handle *out) {
   if (!out) return PSBA_E_INVALID;
   *out = nullptr;
@@ -200,7 +210,7 @@ int psba_create(int device, psba_handle *out) {
   psba_ctx *h = new psba_ctx();
   h->device = device;
   if ((e = hipSetDevice(device)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = create_main_stream(&h->stream)) != hipSuccess ||
       (e = hipMalloc((void **)&h->scal, sizeof(double) * NSCAL)) != hipSuccess ||
       (e = hipHostMalloc((void **)&h->h_scal, sizeof(double) * (NSCAL + 8))) != hipSuccess ||  // (+ the publish stamp)
       (e = hipEventCreateWithFlags(&h->scal_event, hipEventDisableTiming)) != hipSuccess) {
@@ -226,6 +236,10 @@ int psba_destroy(psba_handle h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->k3_event) (void)hipEventDestroy(h->k3_event);
   for (hipEvent_t e : h->chol_events) (void)hipEventDestroy(e);
+  if (h->chol_side) {
+    (void)hipStreamSynchronize(h->chol_side);
+    (void)hipStreamDestroy(h->chol_side);
+  }
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   free_problem_buffers(h);
   dev_free(h->scal);

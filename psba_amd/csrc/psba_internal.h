@@ -176,6 +176,7 @@ struct psba_ctx {
   hipEvent_t scal_event = nullptr;  // recorded behind the scalar copy of psba_backsub_async
   hipStream_t stream2 = nullptr;    // with a communicator: the try's scalar all-reduce + copy run here
   hipEvent_t k3_event = nullptr;    // K3 done (main stream) -> side stream
+  hipStream_t chol_side = nullptr;      // lowest-priority stream of the far updates (look-ahead of the blocked chain)
   std::vector<hipEvent_t> chol_events;  // the look-ahead of the blocked Cholesky chain (two per super-panel)
   bool scal_side = false;           // side-stream work the main stream has not been ordered behind yet
   double *campart = nullptr;    // [nPart][nC][27] per-workgroup camera partial sums
