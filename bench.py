@@ -132,6 +132,10 @@ def pmc_traffic(workload, pair_us):
     code: the traffic is then not quoted (bench.py itself cannot collect PMC counters)."""
     import glob
     best = None
+
+    def graded(name):  # (the runs layout of a clustered-tracks extra in the same profile is another kernel)
+        return ("k_schur_lds<" in name or "k_schur_reduce" in name) and "k_schur_lds_runs" not in name
+
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_profile.json"))):
         try:
             d = json.load(open(f))
@@ -140,12 +144,11 @@ def pmc_traffic(workload, pair_us):
             fetch = write = 0.0
             seen = 0
             for name, c in d["pmc_avg_per_launch_KiB"].items():
-                if ("k_schur_lds" in name or "k_schur_reduce" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                if graded(name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                     fetch += c["FETCH_SIZE"]
                     write += c["WRITE_SIZE"]
                     seen += 1
-            prof_us = sum(float(r["AverageNs"]) for r in d["kernel_stats"]
-                          if "k_schur_lds" in r["Name"] or "k_schur_reduce" in r["Name"]) / 1e3
+            prof_us = sum(float(r["AverageNs"]) for r in d["kernel_stats"] if graded(r["Name"])) / 1e3
             if seen == 2:
                 best = {"bytes": (2 * fetch + write) * 1024.0, "file": os.path.basename(f), "fetch_kib_raw": fetch,
                         "write_kib_raw": write, "profile_pair_us": prof_us, "git_head": d.get("git_head")}

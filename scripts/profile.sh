@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export PSBA_BENCH_NO_CFG5=1  # the full-size cfg5 extra of the default line is not part of the profiled workload
+export PSBA_BENCH_NO_CFG5=1 PSBA_BENCH_NO_CLUSTERED=1  # the extras of the default line are not part of the profiled workload
 ARGS="$REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log

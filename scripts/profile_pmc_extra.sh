@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export PSBA_BENCH_NO_CFG5=1
+export PSBA_BENCH_NO_CFG5=1 PSBA_BENCH_NO_CLUSTERED=1  # the extras of the default line are not part of the profiled workload
 ARGS="$REPO/bench.py --steps 10 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS -f csv -d $OUT/pmc_lds -- python3 $ARGS > /dev/null 2> $OUT/pmc_lds.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -f csv -d $OUT/pmc_valu -- python3 $ARGS > /dev/null 2> $OUT/pmc_valu.log

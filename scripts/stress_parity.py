@@ -27,6 +27,9 @@ while time.time() - t0 < budget:
     sch = o.schur(lin, mu)
     os.environ.pop("PSBA_SCHUR_SPLIT", None)
     os.environ.pop("PSBA_SCHUR_BLOCK_GROUPS", None)
+    os.environ.pop("PSBA_SCHUR_RUNS", None)
+    if rng.random() < 0.3:  # round 4: the runs layout of K2's items, forced (row-aligned groups only)
+        os.environ["PSBA_SCHUR_RUNS"] = "1"
     if rng.random() < 0.3:  # block-range groups (also where row-aligned ones would do), several slabs per group
         os.environ["PSBA_SCHUR_BLOCK_GROUPS"] = "1"
         os.environ["PSBA_SCHUR_SPLIT"] = str(int(rng.integers(1, 4)))
