@@ -407,13 +407,16 @@ int psba_chol_dist_finish(psba_handle h);
  * (no device needed).  The reference decides the same placement per launch through its
  * blkIdx_buffer look-ups (CL_files/compute_S.cl:13-22); here it is data that can be checked.
  * info[0..5] = groups, workgroups, item slots, products, slab doubles, blocks nC(nC+1)/2.
- * psba_schur_plan_copy: items[info[2]]; wg[info[1]][7] = group, blocks in partition, obs0, pt0,
- * first item, end item, slab offset; blockpos[info[5]]; glo[groups+1]: group g owns the blocks
+ * psba_schur_plan_copy: items[info[2]]; wg[info[1]][8] = group, blocks in partition, obs0, pt0,
+ * first item, end item, slab offset, end of the pair items (the list begins with items that carry
+ * two products of one observation a -- partners a - boff and a - boff + 1 -- as 18 bits a - obs0,
+ * 16 bits i - pt0, 8 bits boff, 10 + 10 bits block positions; the single-product items follow:
+ * 24 / 22 / 8 / 10 bits); blockpos[info[5]]; glo[groups+1]: group g owns the blocks
  * [glo[g], glo[g+1]) of the canonical order j (j + 1) / 2 + k.  Any pointer may be NULL. */
 typedef struct psba_schur_plan *psba_schur_plan_t;
 psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, const int *iidx,
                                          const int *jidx);
-int psba_schur_plan_info(psba_schur_plan_t p, long long info[7]); /* info[6] > 0: the runs layout (items as [turn][512] per workgroup, a thread's consecutive items grouped into runs of one position), number of runs */
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[8]); /* info[6] > 0: the runs layout (items as [turn][512] per workgroup, a thread's consecutive items grouped into runs of one position), number of runs; info[7] = pair items */
 int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long long *wg,
                          int *blockpos, int *glo);
 void psba_schur_plan_destroy(psba_schur_plan_t p);

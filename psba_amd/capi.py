@@ -255,18 +255,18 @@ def partition_points(n_pts, iidx, nranks):
 
 def schur_plan(n_cams, n_pts, iidx, jidx):
     """The static schedule of the S-assembly kernel for a sparsity pattern (host only, no
-    device): dict with groups, items (uint64), wg [nWg,7], blockpos, glo and the counters."""
+    device): dict with groups, items (uint64), wg [nWg,8], blockpos, glo and the counters."""
     iidx = _c(iidx, np.int32)
     jidx = _c(jidx, np.int32)
     p = lib.psba_schur_plan_create(int(n_cams), int(n_pts), int(iidx.size), _i(iidx), _i(jidx))
     if not p:
         raise PsbaError(-1, "psba_schur_plan_create failed")
     try:
-        info = (C.c_longlong * 7)()
+        info = (C.c_longlong * 8)()
         lib.psba_schur_plan_info(p, info)
-        groups, nwg, nslots, products, slab, nblocks, run_tasks = (int(x) for x in info)
+        groups, nwg, nslots, products, slab, nblocks, run_tasks, pair_items = (int(x) for x in info)
         items = np.zeros(nslots, dtype=np.uint64)
-        wg = np.zeros((nwg, 7), dtype=np.int64)
+        wg = np.zeros((nwg, 8), dtype=np.int64)
         blockpos = np.zeros(nblocks, dtype=np.int32)
         glo = np.zeros(groups + 1, dtype=np.int32)
         lib.psba_schur_plan_copy(p, items.ctypes.data_as(C.POINTER(C.c_ulonglong)),
@@ -274,7 +274,7 @@ def schur_plan(n_cams, n_pts, iidx, jidx):
     finally:
         lib.psba_schur_plan_destroy(p)
     return dict(groups=groups, items=items, wg=wg, blockpos=blockpos, glo=glo, products=products,
-                slab_doubles=slab, run_tasks=run_tasks)
+                slab_doubles=slab, run_tasks=run_tasks, pair_items=pair_items)
 
 
 def owner_plan(n_cams, n_pts, iidx, jidx, pattern=None):

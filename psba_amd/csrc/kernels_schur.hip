@@ -194,6 +194,63 @@ __global__ __launch_bounds__(TILE_OBS) void k_schur_long(SchurArgs p, const int 
 // (SCHUR_THREADS, BLK_STRIDE and SchurLdsArgs: schur_lds_args.h)
 
 
+// the a-side of a product: V*^-1 = (V_i + mu I)^-1, Y_a = -W_a V*^-1 (Y carries the sign of the product, so that
+// neither the 36 values nor the e_a terms need a sign flip of their own) and e = Y_a g_b,i
+template <bool DUMP>
+__device__ __forceinline__ void schur_a_side(const SchurLdsArgs &p, int a, int i, double (&v)[6], double g0, double g1,
+                                             double g2, const double (&w)[18], double (&Y)[18], double (&e)[6],
+                                             bool dump_y) {
+  double vi[6];
+  v[0] += p.mu;
+  v[3] += p.mu;
+  v[5] += p.mu;
+  if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
+  if (DUMP) {
+    double *o = p.dbg_Vinv + 9 * (size_t)i;
+    o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
+    o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
+    o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) vi[k] = -vi[k];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+    Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+    Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+    Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+    e[r] = Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2;
+  }
+  if (DUMP && dump_y) {
+#pragma unroll
+    for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = -Y[k];
+  }
+}
+
+// blk += Y W_b^T (6x6, ds_add_f64); the self-product's e_a terms ride in redundant upper-triangle slots (EA_SLOT)
+__device__ __forceinline__ void schur_block_add(double *blk, const double (&Y)[18], const double (&wb)[18], bool self,
+                                                const double (&e)[6]) {
+  // a row of the block at a time: its six values are independent chains of three operations,
+  // formed side by side (one after the other, every operation would wait for the one before)
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    double val[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) val[c] = Y[3 * r] * wb[3 * c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 1], wb[3 * c + 1], val[c]);
+#pragma unroll
+    for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 2], wb[3 * c + 2], val[c]);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      if (r == 0 && c >= 1) val[c] = self ? e[c - 1] : val[c];
+      if (r == 1 && c == 2) val[c] = self ? e[5] : val[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) atomicAdd(&blk[6 * r + c], val[c]);
+  }
+}
+
 // one item = one product Y_a W_b^T of one point; see the schedule above
 template <bool DUMP>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
@@ -205,11 +262,62 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
   for (int t = tid; t < BLK_STRIDE * wg.nblk; t += SCHUR_THREADS) sPart[t] = 0.0;
   __syncthreads();
 
+#ifdef PSBA_BUILD_EXPERIMENTS
+  // ---- pair items (round 4; measured slower, DESIGN 5d: experiments build, PSBA_SCHUR_PAIRS=1):
+  // one observation a, its partners a - boff and a - boff + 1 (adjacent rows of W): the a-side (W_a, V*^-1, Y_a,
+  // the e_a terms) is loaded and formed once for two products ----
+  {
+    const long long s1 = wg.itemD;
+    unsigned long long item_next = (wg.item0 + tid < s1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
+    for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
+      const unsigned long long item = item_next;
+      if (t + SCHUR_THREADS < s1) item_next = p.items[t + SCHUR_THREADS];
+      if (item == SCHUR_NULL_ITEM) continue;
+      const int a = wg.obs0 + (int)(item & ((1u << PAIR_OBS_BITS) - 1));
+      const int i = wg.pt0 + (int)((item >> PAIR_OBS_BITS) & ((1u << PAIR_PT_BITS) - 1));
+      const int boff = (int)((item >> (PAIR_OBS_BITS + PAIR_PT_BITS)) & ((1u << ITEM_BOFF_BITS) - 1));
+      const int pos = (int)((item >> (PAIR_OBS_BITS + PAIR_PT_BITS + ITEM_BOFF_BITS)) & ((1u << ITEM_POS_BITS) - 1));
+      const int pos2 = (int)((item >> (PAIR_OBS_BITS + PAIR_PT_BITS + ITEM_BOFF_BITS + ITEM_POS_BITS)) & ((1u << ITEM_POS_BITS) - 1));
+      const double *pv = p.PV + 9 * (size_t)i;
+      const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
+      const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
+      double v[6], w[18], wb[18];
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = pv[k];
+      const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double2 q = wa[k];
+        w[2 * k] = q.x;
+        w[2 * k + 1] = q.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double2 q = wb2[k];
+        wb[2 * k] = q.x;
+        wb[2 * k + 1] = q.y;
+      }
+      double Y[18], e[6];
+      schur_a_side<DUMP>(p, a, i, v, g0, g1, g2, w, Y, e, boff == 1);
+      schur_block_add(sPart + BLK_STRIDE * pos, Y, wb, false, e);
+      // the second partner's row takes the registers of the first (36 VGPRs more would spill at 4 waves per SIMD);
+      // the compiler must not hoist these loads above the first product
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const double2 q = wb2[9 + k];
+        wb[2 * k] = q.x;
+        wb[2 * k + 1] = q.y;
+      }
+      schur_block_add(sPart + BLK_STRIDE * pos2, Y, wb, boff == 1, e);
+    }
+  }
+#endif
   const long long s1 = wg.item1;
   // the next item word is fetched a turn ahead: its latency would otherwise sit in front of the
   // record loads of every turn (a wave has only about six turns)
-  unsigned long long item_next = (wg.item0 + tid < s1) ? p.items[wg.item0 + tid] : SCHUR_NULL_ITEM;
-  for (long long t = wg.item0 + tid; t < s1; t += SCHUR_THREADS) {
+  unsigned long long item_next = (wg.itemD + tid < s1) ? p.items[wg.itemD + tid] : SCHUR_NULL_ITEM;
+  for (long long t = wg.itemD + tid; t < s1; t += SCHUR_THREADS) {
     const unsigned long long item = item_next;
     if (t + SCHUR_THREADS < s1) item_next = p.items[t + SCHUR_THREADS];
     if (item == SCHUR_NULL_ITEM) continue;
@@ -221,7 +329,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
     const double *pv = p.PV + 9 * (size_t)i;
     const double2 *wa = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)a);
     const double2 *wb2 = reinterpret_cast<const double2 *>(p.W + 18 * (size_t)(a - boff));
-    double v[6], vi[6], w[18], wb[18];
+    double v[6], w[18], wb[18];
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = pv[k];
     const double g0 = pv[6], g1 = pv[7], g2 = pv[8];
@@ -237,55 +345,10 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_lds(SchurLdsArgs p) {
       wb[2 * k] = q.x;
       wb[2 * k + 1] = q.y;
     }
-    v[0] += p.mu;
-    v[3] += p.mu;
-    v[5] += p.mu;
-    if (sym3_inverse(v, vi)) p.status[0] = p.try_id;
-    if (DUMP) {
-      double *o = p.dbg_Vinv + 9 * (size_t)i;
-      o[0] = vi[0]; o[1] = vi[1]; o[2] = vi[2];
-      o[3] = vi[1]; o[4] = vi[3]; o[5] = vi[4];
-      o[6] = vi[2]; o[7] = vi[4]; o[8] = vi[5];
-    }
     const bool self = boff == 0;
-    // Y carries the sign of the product: Y = -W_a V*^-1, so that neither the 36 values nor the
-    // e_a terms need a sign flip of their own
-#pragma unroll
-    for (int k = 0; k < 6; k++) vi[k] = -vi[k];
     double Y[18], e[6];
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double w0 = w[3 * r], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
-      Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
-      Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
-      Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
-      e[r] = Y[3 * r] * g0 + Y[3 * r + 1] * g1 + Y[3 * r + 2] * g2;
-    }
-    if (DUMP && self) {
-#pragma unroll
-      for (int k = 0; k < 18; k++) p.dbg_Y[18 * (size_t)a + k] = -Y[k];
-    }
-    double *blk = sPart + BLK_STRIDE * pos;
-    // a row of the block at a time: its six values are independent chains of three operations,
-    // formed side by side (one after the other, every operation would wait for the one before)
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      double val[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) val[c] = Y[3 * r] * wb[3 * c];
-#pragma unroll
-      for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 1], wb[3 * c + 1], val[c]);
-#pragma unroll
-      for (int c = 0; c < 6; c++) val[c] = fma(Y[3 * r + 2], wb[3 * c + 2], val[c]);
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        // the self-product's e_a terms ride in redundant upper-triangle slots (EA_SLOT)
-        if (r == 0 && c >= 1) val[c] = self ? e[c - 1] : val[c];
-        if (r == 1 && c == 2) val[c] = self ? e[5] : val[c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) atomicAdd(&blk[6 * r + c], val[c]);
-    }
+    schur_a_side<DUMP>(p, a, i, v, g0, g1, g2, w, Y, e, self);
+    schur_block_add(sPart + BLK_STRIDE * pos, Y, wb, self, e);
   }
   __syncthreads();
   // two doubles per thread and step: 36 is even, so a pair never straddles a block, and the
@@ -774,7 +837,7 @@ static int launch_schur_lds(psba_ctx *h, double mu, bool dump) {
         launched = true;
       }
 #ifdef PSBA_BUILD_EXPERIMENTS
-      if (!launched && !dump && mode > 0) launched = launch_schur_lds_mode(mode, G, B, lds, h->stream, a);  // kernels_schur_modes.hip
+      if (!launched && !dump && mode > 0 && !h->schur_pairs) launched = launch_schur_lds_mode(mode, G, B, lds, h->stream, a);  // kernels_schur_modes.hip
 #endif
       (void)mode;
       if (launched) {

@@ -559,6 +559,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
     SchurPlanHost plan;
     TRY(build_schur_plan(h, nCams, n3Dpts, n2Dprojs, iidx, jidx, ptr.data(), plan));
     h->schur_runs = h->nGroups > 0 && plan.runs;
+    h->schur_pairs = h->nGroups > 0 && plan.pair_items > 0;
     if (h->nGroups) {
       TRY(dev_alloc(h, &h->items, plan.items.size() ? plan.items.size() : 1));
       TRY(dev_alloc(h, &h->wg, plan.wgs.size()));
@@ -1630,7 +1631,7 @@ psba_schur_plan_t psba_schur_plan_create(int nCams, int n3Dpts, int n2Dprojs, co
   return p;
 }
 
-int psba_schur_plan_info(psba_schur_plan_t p, long long info[7]) {
+int psba_schur_plan_info(psba_schur_plan_t p, long long info[8]) {
   if (!p || !info) return PSBA_E_INVALID;
   info[0] = p->ctx.nGroups;
   info[1] = p->ctx.nGroups ? p->ctx.nWg : 0;
@@ -1639,6 +1640,7 @@ int psba_schur_plan_info(psba_schur_plan_t p, long long info[7]) {
   info[4] = (long long)p->plan.slab_doubles;
   info[5] = p->nBlocks;
   info[6] = p->plan.runs ? p->plan.tasks : 0;  // > 0: the runs layout ([turn][512] per workgroup), number of runs
+  info[7] = p->plan.pair_items;                // items that carry two products of one observation
   return PSBA_OK;
 }
 
@@ -1649,9 +1651,9 @@ int psba_schur_plan_copy(psba_schur_plan_t p, unsigned long long *items, long lo
   if (wg)
     for (size_t k = 0; k < p->plan.wgs.size(); k++) {
       const psba::SchurWg &w = p->plan.wgs[k];
-      long long *o = wg + 7 * k;
+      long long *o = wg + 8 * k;
       o[0] = w.group; o[1] = w.nblk; o[2] = w.obs0; o[3] = w.pt0;
-      o[4] = w.item0; o[5] = w.item1; o[6] = (long long)w.slab_off;
+      o[4] = w.item0; o[5] = w.item1; o[6] = (long long)w.slab_off; o[7] = w.itemD;
     }
   if (blockpos) std::copy(p->plan.blockpos.begin(), p->plan.blockpos.end(), blockpos);
   if (glo)  // block ranges: group g owns the blocks [glo[g], glo[g + 1]) of the canonical order tri(j) + k

@@ -54,7 +54,11 @@ struct SchurWg {
   int obs0, pt0;        // the items' observation / point numbers are relative to these
   long long item0, item1;
   unsigned long long slab_off;  // where this workgroup's partition goes in psba_ctx::slab
+  long long itemD;      // [item0, itemD): pair items (one a-side, two partners, see PAIR_*_BITS); [itemD, item1): one product each
 };
+// a pair item: one observation a and its partners a - boff and a - boff + 1 of the same point (W_a, V*^-1, Y_a and
+// the e_a terms are formed once for two products): a - obs0, i - pt0, boff >= 1, the two block positions
+constexpr int PAIR_OBS_BITS = 18, PAIR_PT_BITS = 16;  // (+ ITEM_BOFF_BITS + 2 * ITEM_POS_BITS = 62 bits)
 constexpr unsigned long long SCHUR_NULL_ITEM = ~0ull;
 // what k_schur_reduce needs to know about the group a run of 16 partition positions belongs to
 struct ReduceGroup {
@@ -135,6 +139,7 @@ struct SchurPlanHost {
   // thread's consecutive items grouped into runs of one block position; tasks = number of such runs
   bool runs = false;
   long long tasks = 0;
+  long long pair_items = 0;  // rows layout: items that carry two products of one observation (SchurWg::itemD)
 };
 constexpr int RUN_THREADS = 512;  // threads of a workgroup of k_schur_lds_runs: 192 VGPRs with the 36 accumulators, two waves per SIMD (768 threads = 168 VGPRs spill 27 registers: 85 against 59 us)
 constexpr int RUN_MAX = 32;       // products a lane sums in registers before it touches the LDS at the latest
@@ -237,6 +242,7 @@ struct psba_ctx {
   // block-sparse S + preconditioned CG (psba_set_solver, kernels_pcg.hip)
   int solver = 0;               // PSBA_SOLVER_*
   bool schur_runs = false;  // K2's items are in the runs layout (k_schur_lds_runs)
+  bool schur_pairs = false; // K2's item lists begin with pair items (SchurWg::itemD)
   int cnp = 6;  // parameters per camera: 6 (fixed intrinsics, the reference's kernels) or 11 (psba_set_camera_model: free intrinsics)
   double pcg_tol = 1e-10;
   int pcg_maxit = 500, pcg_iters = 0;

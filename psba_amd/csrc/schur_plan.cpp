@@ -236,6 +236,13 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
   out.runs = n_tasks_probe > 0 && (double)total_items / (double)n_tasks_probe >= 6.0 && !block_ranges;
   if (const char *e = getenv("PSBA_SCHUR_RUNS")) out.runs = atoi(e) != 0 && !block_ranges;
   out.tasks = 0;
+  out.pair_items = 0;
+  // pair items (one observation, two partners): built and measured in round 4 -- 41.5 against
+  // 38.5 us on venice-shaped -- so only the experiments build deals them, on request
+  bool use_pairs = false;
+#ifdef PSBA_BUILD_EXPERIMENTS
+  if (const char *e = getenv("PSBA_SCHUR_PAIRS")) use_pairs = atoi(e) != 0 && !block_ranges && !out.runs;
+#endif
   struct WgTmp { SchurWg w; double where; };
   std::vector<WgTmp> wgs;
   out.items.clear();
@@ -299,58 +306,111 @@ int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx
         out.items.resize(base + T * RUN_THREADS, SCHUR_NULL_ITEM);
         for (int thr = 0; thr < RUN_THREADS; thr++)
           for (size_t t = 0; t < list[(size_t)thr].size(); t++) out.items[base + t * RUN_THREADS + thr] = list[(size_t)thr][t];
-        w.item0 = (long long)base;
+        w.item0 = w.itemD = (long long)base;
         w.item1 = (long long)out.items.size();
         wgs.push_back({w, n ? (double)(r0 + r1) / (2.0 * (double)n) : 0.0});
         continue;
       }
-      // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows)
-      size_t closed = 0;  // rows [0, closed) are final
-      std::vector<uint16_t> mask, mask2;  // bank pairs used once / twice in a row
-      std::vector<int> fill;
+      // deal the range into rows of 16 with distinct bank pairs (first fit over a window of open rows).  A slot
+      // has one block position (one product) or two (a pair item: two products, added in two phases -- the 16
+      // lanes must hit 16 different bank pairs in each phase)
+      struct Slot { unsigned long long enc; int pos[2]; int np; };
       // block ranges (many cameras): a group holds at most one diagonal block, which alone receives
       // as many items as all its other blocks together (every observation's self-product).  Lanes on
       // one address are serialised by the LDS whichever rows they sit in, so an item may always
       // join a row that already has its very position: without this such lists are rows of two
       // items and fourteen holes (fill 0.54 at cfg5)
       const bool same_pos_ok = block_ranges;
-      std::vector<std::vector<int>> rowpos;
-      auto row_ptr = [&](size_t r) { return out.items.data() + base + r * ROW; };
+      auto deal = [&](const std::vector<Slot> &slots) {
+        const size_t base_rows = out.items.size();
+        size_t closed = 0;  // rows [0, closed) are final
+        std::vector<uint16_t> mask[2], mask2[2];  // per phase: bank pairs used once / twice in a row
+        std::vector<int> fill;
+        std::vector<std::vector<int>> rowpos;
+        auto row_ptr = [&](size_t r) { return out.items.data() + base_rows + r * ROW; };
+        for (const Slot &sl : slots) {
+          uint16_t bit[2] = {(uint16_t)(1u << (sl.pos[0] % ROW)), (uint16_t)(sl.np > 1 ? 1u << (sl.pos[1] % ROW) : 0)};
+          auto has_pos = [&](size_t row) {
+            if (!same_pos_ok || sl.np > 1) return false;
+            for (int q : rowpos[row])
+              if (q == sl.pos[0]) return true;
+            return false;
+          };
+          auto clean = [&](size_t row) {
+            for (int ph = 0; ph < sl.np; ph++)
+              if ((mask[ph][row] & bit[ph]) && !has_pos(row)) return false;
+            return true;
+          };
+          auto once_more = [&](size_t row) {  // every phase either clean or a first repeat of its bank pair
+            for (int ph = 0; ph < sl.np; ph++)
+              if ((mask[ph][row] & bit[ph]) && (mask2[ph][row] & bit[ph])) return false;
+            return true;
+          };
+          size_t r = closed;
+          const size_t nrows = fill.size();
+          while (r < nrows && (fill[r] == ROW || !clean(r))) r++;
+          if (r == nrows && DUPS && nrows - closed >= (size_t)WINDOW) {
+            // no clean slot and the window is full: rather than opening a row (and closing the
+            // oldest one with holes), let a bank pair be used twice -- one extra LDS pass for
+            // that row of 16 lanes instead of idle lanes
+            r = closed;
+            while (r < nrows && (fill[r] == ROW || !once_more(r))) r++;
+          }
+          if (r == nrows) {
+            for (int ph = 0; ph < 2; ph++) {
+              mask[ph].push_back(0);
+              mask2[ph].push_back(0);
+            }
+            fill.push_back(0);
+            rowpos.emplace_back();
+            out.items.resize(base_rows + fill.size() * ROW, SCHUR_NULL_ITEM);
+          }
+          row_ptr(r)[fill[r]++] = sl.enc;
+          for (int ph = 0; ph < sl.np; ph++) {
+            if (mask[ph][r] & bit[ph]) mask2[ph][r] |= bit[ph];
+            mask[ph][r] |= bit[ph];
+          }
+          if (same_pos_ok) rowpos[r].push_back(sl.pos[0]);
+          while (closed < fill.size() && (fill[closed] == ROW || fill.size() - closed > (size_t)WINDOW)) closed++;
+        }
+      };
+      // pair items (round 4): consecutive products of one observation a (partners b, b + 1) share W_a, V*^-1, Y_a
+      // and the e_a terms.  Row-aligned groups keep all partners of an observation in its camera's group; the
+      // range's extent must fit the pair fields.
+      const bool pairs = use_pairs && r1 > r0 && raw[g][r1 - 1].a - w.obs0 < (1 << PAIR_OBS_BITS) &&
+                         raw[g][r1 - 1].i - w.pt0 < (1 << PAIR_PT_BITS);
+      std::vector<Slot> dbl, sgl;
+      size_t run_end = r0;  // end of the products of it.a inside the range
+      bool odd_done = false;
       for (size_t t = r0; t < r1; t++) {
         const Raw &it = raw[g][t];
-        const unsigned long long enc = (unsigned long long)(it.a - w.obs0) |
-                                       ((unsigned long long)(it.i - w.pt0) << ITEM_OBS_BITS) |
-                                       ((unsigned long long)it.boff << (ITEM_OBS_BITS + ITEM_PT_BITS)) |
-                                       ((unsigned long long)it.pos << (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS));
-        const uint16_t bit = (uint16_t)(1u << (it.pos % ROW));
-        size_t r = closed;
-        auto has_pos = [&](size_t row) {
-          if (!same_pos_ok) return false;
-          for (int q : rowpos[row])
-            if (q == it.pos) return true;
-          return false;
-        };
-        while (r < mask.size() && (fill[r] == ROW || ((mask[r] & bit) && !has_pos(r)))) r++;
-        if (r == mask.size() && DUPS && mask.size() - closed >= (size_t)WINDOW) {
-          // no clean slot and the window is full: rather than opening a row (and closing the
-          // oldest one with holes), let a bank pair be used twice -- one extra LDS pass for
-          // that row of 16 lanes instead of idle lanes
-          r = closed;
-          while (r < mask.size() && (fill[r] == ROW || (mask2[r] & bit))) r++;
-          if (r < mask.size()) mask2[r] |= bit;
+        if (t == run_end) {
+          while (run_end < r1 && raw[g][run_end].a == it.a) run_end++;
+          odd_done = false;
         }
-        if (r == mask.size()) {
-          mask.push_back(0);
-          mask2.push_back(0);
-          fill.push_back(0);
-          rowpos.emplace_back();
-          out.items.resize(base + mask.size() * ROW, SCHUR_NULL_ITEM);
+        // an odd number of products: the FIRST one goes alone (the last one is the self-product, and the diagonal
+        // blocks of a group are too few positions to fill rows of 16 bank pairs with)
+        const bool alone = ((run_end - t) & 1) && !odd_done;
+        if (alone) odd_done = true;
+        if (pairs && !alone && t + 1 < run_end) {
+          const Raw &nx = raw[g][t + 1];  // (the list runs b upwards: nx.boff == it.boff - 1)
+          dbl.push_back({(unsigned long long)(it.a - w.obs0) | ((unsigned long long)(it.i - w.pt0) << PAIR_OBS_BITS) |
+                             ((unsigned long long)it.boff << (PAIR_OBS_BITS + PAIR_PT_BITS)) |
+                             ((unsigned long long)it.pos << (PAIR_OBS_BITS + PAIR_PT_BITS + ITEM_BOFF_BITS)) |
+                             ((unsigned long long)nx.pos << (PAIR_OBS_BITS + PAIR_PT_BITS + ITEM_BOFF_BITS + ITEM_POS_BITS)),
+                         {it.pos, nx.pos}, 2});
+          t++;
+          continue;
         }
-        row_ptr(r)[fill[r]++] = enc;
-        mask[r] |= bit;
-        if (same_pos_ok) rowpos[r].push_back(it.pos);
-        while (closed < mask.size() && (fill[closed] == ROW || mask.size() - closed > (size_t)WINDOW)) closed++;
+        sgl.push_back({(unsigned long long)(it.a - w.obs0) | ((unsigned long long)(it.i - w.pt0) << ITEM_OBS_BITS) |
+                           ((unsigned long long)it.boff << (ITEM_OBS_BITS + ITEM_PT_BITS)) |
+                           ((unsigned long long)it.pos << (ITEM_OBS_BITS + ITEM_PT_BITS + ITEM_BOFF_BITS)),
+                       {it.pos, 0}, 1});
       }
+      deal(dbl);
+      w.itemD = (long long)out.items.size();
+      deal(sgl);
+      out.pair_items += (long long)dbl.size();
       w.item0 = (long long)base;
       w.item1 = (long long)out.items.size();
       wgs.push_back({w, n ? (double)(r0 + r1) / (2.0 * (double)n) : 0.0});

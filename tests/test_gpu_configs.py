@@ -1043,7 +1043,7 @@ def test_tail_kernel_experiment(tail, monkeypatch):
         assert abs(outs[1][1] - outs[0][1]) <= 1e-12 * outs[0][1]
 
 
-@pytest.mark.parametrize("cluster,force", [(16, None), (1, "1"), (16, "0")])
+@pytest.mark.parametrize("cluster,force", [(16, None), (1, "1"), (16, "0"), (1, "pairs")])
 def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
     """K2's runs layout (k_schur_lds_runs; round 4): on clustered tracks a thread sums a run of one block's products
     in registers and touches the LDS once per run.  S, e_a, dpa and the try's scalars against the ORACLE on a
@@ -1052,6 +1052,14 @@ def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
     row layout forced (PSBA_SCHUR_RUNS=0)."""
     import psba_amd
     import psba_amd.synth as synth
+    pairs = force == "pairs"
+    if pairs:
+        # round 4's pair items (one observation, two partners per item; measured slower, experiments build only:
+        # PSBA_BUILD_EXPERIMENTS=1 python psba_amd/build.py, PSBA_LIB=.../libpsba_hip_exp.so) through the same checks
+        if not psba_amd.capi.HAS_EXPERIMENTS:
+            pytest.skip("experiment build only (PSBA_BUILD_EXPERIMENTS=1)")
+        monkeypatch.setenv("PSBA_SCHUR_PAIRS", "1")
+        force = None
     if force is not None:
         monkeypatch.setenv("PSBA_SCHUR_RUNS", force)
     prob = synth.venice_shaped(n_pts=12000, cluster=cluster)
@@ -1066,6 +1074,7 @@ def test_runs_layout_of_the_schur_assembly(cluster, force, monkeypatch):
     assert h.schur_path() == 0
     plan = psba_amd.capi.schur_plan(prob["nC"], prob["nP"], prob["iidx"], prob["jidx"])
     assert (plan["run_tasks"] > 0) == (force == "1" or (force is None and cluster > 1))
+    assert (plan["pair_items"] > 0.3 * plan["products"]) == pairs and (pairs or plan["pair_items"] == 0)
     h.linearize(1.0, 1.0)
     h.schur_assemble(mu)
     nA = o.nA

@@ -104,11 +104,30 @@ def _check_plan(nC, nP, iidx, jidx):
     slabs = set()
     runs = plan["run_tasks"] > 0
     n_runs = 0
+    n_pairs = 0
+    products_of = {}
     for w in wg:
-        g, nblk, obs0, pt0, s0, s1, slab = (int(x) for x in w)
-        assert s0 % 16 == 0 and s1 % 16 == 0 and (g, slab) not in slabs
+        g, nblk, obs0, pt0, s0, s1, slab, sD = (int(x) for x in w)
+        assert s0 % 16 == 0 and s1 % 16 == 0 and sD % 16 == 0 and s0 <= sD <= s1 and (g, slab) not in slabs
         slabs.add((g, slab))
-        it = items[s0:s1]
+        # pair items first: one observation a, partners a - boff and a - boff + 1, two block positions
+        it = items[s0:sD]
+        live = it != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert not runs or sD == s0
+        a2 = obs0 + (it & np.uint64(0x3FFFF)).astype(np.int64)                      # 18 bits
+        i2 = pt0 + ((it >> np.uint64(18)) & np.uint64(0xFFFF)).astype(np.int64)     # 16 bits
+        boff2 = ((it >> np.uint64(34)) & np.uint64(0xFF)).astype(np.int64)
+        p2a = ((it >> np.uint64(42)) & np.uint64(0x3FF)).astype(np.int64)
+        p2b = ((it >> np.uint64(52)) & np.uint64(0x3FF)).astype(np.int64)
+        assert ((it >> np.uint64(62))[live] == 0).all() and (boff2[live] >= 1).all()
+        for r in range(0, len(it), 16):
+            for pp in (p2a, p2b):  # each of the two phases of atomics on its own
+                q = np.unique(pp[r:r + 16][live[r:r + 16]]) % 16
+                assert np.bincount(q, minlength=16).max() <= 2
+        n_pairs += int(live.sum())
+        pa, pi, pboff, ppos = (np.concatenate([a2[live], a2[live]]), np.concatenate([i2[live], i2[live]]),
+                               np.concatenate([boff2[live], boff2[live] - 1]), np.concatenate([p2a[live], p2b[live]]))
+        it = items[sD:s1]
         live = it != np.uint64(0xFFFFFFFFFFFFFFFF)
         a = obs0 + (it & np.uint64(0xFFFFFF)).astype(np.int64)          # 24 bits
         i = pt0 + ((it >> np.uint64(24)) & np.uint64(0x3FFFFF)).astype(np.int64)  # 22 bits
@@ -133,7 +152,9 @@ def _check_plan(nC, nP, iidx, jidx):
             for r in range(0, len(it), 16):
                 q = np.unique(p[r:r + 16][live[r:r + 16]]) % 16  # lanes on one address serialise wherever they sit
                 assert np.bincount(q, minlength=16).max() <= 2  # a bank pair: at most two addresses per row
-        a, i, boff, p = a[live], i[live], boff[live], p[live]
+        a, i, boff, p = (np.concatenate([a[live], pa]), np.concatenate([i[live], pi]), np.concatenate([boff[live], pboff]),
+                         np.concatenate([p[live], ppos]))
+        products_of[(g, slab)] = len(a)
         b = a - boff
         assert (iidx[a] == i).all() and (iidx[b] == i).all() and (b >= ptr[i]).all()
         ja, jb = jidx[a].astype(np.int64), jidx[b].astype(np.int64)
@@ -147,11 +168,26 @@ def _check_plan(nC, nP, iidx, jidx):
     assert len(seen) == want == plan["products"]
     if runs:  # (two runs of one position that meet in a thread's list merge: never more runs than the plan says)
         assert 0 < n_runs <= plan["run_tasks"]
-    # balance: item counts of the workgroups of one group differ by at most one
+    assert n_pairs == plan["pair_items"]
+    # balance: product counts of the workgroups of one group differ by at most one
     for g in range(plan["groups"]):
-        n = [int(((items[int(w[4]):int(w[5])]) != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()) for w in wg if w[0] == g]
+        n = [v for (gg, _), v in products_of.items() if gg == g]
         assert max(n) - min(n) <= 1
     return plan
+
+
+def test_schur_plan_pair_items(problems, monkeypatch):
+    """Round 4's pair items (experiments build only): every product once, each of the two phases of atomics with at
+    most two addresses per bank pair and row, most products carried by pairs."""
+    from psba_amd import capi, synth
+    if not capi.HAS_EXPERIMENTS:
+        pytest.skip("experiment build only (PSBA_BUILD_EXPERIMENTS=1)")
+    monkeypatch.setenv("PSBA_SCHUR_PAIRS", "1")
+    pr = synth.venice_shaped(n_pts=12000)
+    plan = _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
+    assert 2 * plan["pair_items"] > 0.8 * plan["products"]
+    pr = problems["54cams"]
+    _check_plan(pr["nC"], pr["nP"], np.asarray(pr["iidx"]), np.asarray(pr["jidx"]))
 
 
 def test_schur_plan_small(problems):
