@@ -683,6 +683,88 @@ __global__ __launch_bounds__(256) void k_cholg_trsm_block(const double *Lw, doub
   }
 }
 
+// The same block solve with FOUR waves per 16-row tile row.  One wave per tile row is bound by its own SIMD: 16 x NB^2
+// flops = 1248 MFMAs of 64 cycles at NB = 384, ~46 us at best and ~80 measured, however few rows there are -- and in
+// the look-ahead chain this kernel sits between a super-panel's steps and its update.  Here the wave k mod 4 owns
+// column block k; right-looking inside the workgroup: the owner finishes X_k = C_k L_kk^-T and publishes it in LDS
+// (operand layout), every wave subtracts X_k L_k'k^T from the blocks k' > k it owns -- the owner of k + 1 first, which
+// then finishes and publishes X_k+1 before it turns to its other blocks.  Per column block the critical path is
+// 16 + 16 MFMAs and two LDS transposes; the other 1200 MFMAs run beside it on the other three SIMDs.
+template <int NBK>
+__global__ __launch_bounds__(256) void k_cholg_trsm_block4(const double *Lw, double *Lx, int ld, int J, int T_first,
+                                                           int nTall, const double *linv) {
+  __shared__ double sA[4][16][XS];  // a wave's scratch: accumulator layout -> operand layout
+  __shared__ double sX[2][16][XS];  // the published X_k (operand layout), by parity of k
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int T = T_first + blockIdx.x;
+  if (T >= nTall) return;
+  constexpr int NQ = (NBK + 3) / 4;
+  d4 cl[NQ], cr[NQ];  // the pieces of C of the blocks 4 q + wave, accumulator layout (two 16x16 halves)
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int k = 4 * q + wave, j = J + GB * k;
+    if (k < NBK) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        cl[q][r] = Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + li];
+        cr[q][r] = Lw[(size_t)(16 * T + lk + 4 * r) * ld + j + 16 + li];
+      }
+    }
+  }
+  // finish block k (mine, fully updated): X_k = C_k L_kk^-T, stored and published
+  auto finish = [&](int q, int k) {
+    const int j = J + GB * k;
+    const double *Li = linv + (size_t)(j / GB) * GB * GB;
+    const Row8 p = load_row8(Li + (size_t)li * GB + 8 * lk), q8 = load_row8(Li + (size_t)(16 + li) * GB + 8 * lk);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sA[wave][lk + 4 * r][li] = cl[q][r];
+      sA[wave][lk + 4 * r][16 + li] = cr[q][r];
+    }
+    const Row8 a = load_row8(&sA[wave][li][8 * lk]);
+    d4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t], p.v[t], x0, 0, 0, 0);
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t], q8.v[t], y0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t + 1], p.v[t + 1], x1, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v[t + 1], q8.v[t + 1], y1, 0, 0, 0);
+    }
+    const d4 xl = x0 + x1, xr = y0 + y1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sX[k & 1][lk + 4 * r][li] = xl[r];
+      sX[k & 1][lk + 4 * r][16 + li] = xr[r];
+    }
+    store_x_tile(Lx, ld, j, T, li, lk, xl, xr);
+  };
+  // block k2 (mine) minus X_k L_k2,k^T
+  auto apply = [&](int q, int k2, int k, const Row8 &X) {
+    const double *Lkk = Lx + (size_t)(J + GB * k2) * ld + J + GB * k;  // L_D block (k2, k)
+    const Row8 b0 = load_row8(Lkk + (size_t)li * ld + 8 * lk), b1 = load_row8(Lkk + (size_t)(16 + li) * ld + 8 * lk);
+    cl[q] = update_mfma(cl[q], X, b0);
+    cr[q] = update_mfma(cr[q], X, b1);
+  };
+  if (wave == 0) finish(0, 0);
+#pragma unroll
+  for (int k = 0; k < NBK; k++) {
+    __syncthreads();  // X_k is published (and everybody is done with the buffer X_k+1 will take)
+    if (k + 1 >= NBK) break;
+    const Row8 X = load_row8(&sX[k & 1][li][8 * lk]);
+    // my blocks behind k, nearest first; the owner of k + 1 publishes X_k+1 as soon as its block is complete
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int k2 = 4 * q + wave;
+      if (k2 > k && k2 < NBK) {
+        apply(q, k2, k, X);
+        if (k2 == k + 1) finish(q, k2);
+      }
+    }
+  }
+}
+
 // backward solve  L^T x = y  (y = L^-1 e_a sits in row n32), one workgroup, blocks of 32:
 // x_J = L_dd^-T y_J is a 32x32 mat-vec with the stored inverse (no dependent chain), then all
 // threads apply y[c] -= sum_r L[j+r][c] x_J[r]; the L values of that update do not depend on x
@@ -1251,7 +1333,13 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
       hipLaunchKernelGGL(k_cholg_update_cols, dim3(1 + (unsigned)((tiles + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, j,
                          nTs, TE, linv, h->status);
   }
-  if (diag_only) {  // the rows below the super-panel (and the e_a row): X = C L_D^-T in one pass
+  if (diag_only && !getenv("PSBA_CHOL_TRSM_WAVE")) {  // the rows below the super-panel (and the e_a row): X = C L_D^-T in one pass
+    const dim3 g(nT - JE / 16), b(256);  // four waves per tile row (PSBA_CHOL_TRSM_WAVE=1: one wave, the first form)
+    if (nbk == 4) hipLaunchKernelGGL(k_cholg_trsm_block4<4>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 8) hipLaunchKernelGGL(k_cholg_trsm_block4<8>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 12) hipLaunchKernelGGL(k_cholg_trsm_block4<12>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+    if (nbk == 16) hipLaunchKernelGGL(k_cholg_trsm_block4<16>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
+  } else if (diag_only) {
     const dim3 g((nT - JE / 16 + 3) / 4), b(256);
     if (nbk == 4) hipLaunchKernelGGL(k_cholg_trsm_block<4>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
     if (nbk == 8) hipLaunchKernelGGL(k_cholg_trsm_block<8>, g, b, 0, s, Lw, Lx, ld, J, JE / 16, nT, linv);
