@@ -496,12 +496,20 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide4(double *Lw, double *
     mc = __builtin_amdgcn_readfirstlane((int)(idx % ncolb));
     if (mc > m) return;
   } else {
-    m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-    while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
-    while ((long long)m * (m + 1) / 2 > idx) m--;
-    m = __builtin_amdgcn_readfirstlane(m);
-    mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+    // the blocks below the diagonal first, row by row; the diagonal blocks (10 of 16 tiles: shorter) last, so
+    // that the launch's last, partly filled round of waves is made of the short ones
+    const long long nfull = MR * (MR - 1) / 2;
+    if (idx < nfull) {
+      m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+      while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+      while ((long long)m * (m + 1) / 2 > idx) m--;
+      mc = __builtin_amdgcn_readfirstlane((int)(idx - (long long)m * (m + 1) / 2));
+      m = __builtin_amdgcn_readfirstlane(m + 1);
+    } else {
+      m = mc = __builtin_amdgcn_readfirstlane((int)(idx - nfull));
+    }
   }
+
   if (nranks > 0 && (Tw / 4 + mc) % nranks != rank) return;
   const int TR0 = Tw + 4 * m, TC0 = Tw + 4 * mc;
   const int last = nT - 2;  // last tile row / column of the square
