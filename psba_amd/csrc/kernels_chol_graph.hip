@@ -1299,6 +1299,13 @@ static ChainShape chain_shape(const psba_ctx *h) {
   return c;
 }
 
+// a pause on a stream: one wave sleeps until `ticks` of the 100 MHz wall clock have passed (look-ahead chain: the far
+// update starts a few microseconds after the near one, see enqueue_superpanel)
+__global__ void k_cholg_pause(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  for (int i = 0; i < 4096 && (long long)wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(8);
+}
+
 // one super-panel [J, J + NB) of the two-level chain: its 32-column steps, which update only the
 // super-panel's remaining columns (all rows below), then ONE K = NB update of everything to its
 // right.  nranks > 0: that update only for this rank's 64-column blocks (k_cholg_update_wide4); 0: replicated.
@@ -1370,6 +1377,12 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
       hipLaunchKernelGGL(k_cholg_update_wide4, dim3(1 + (unsigned)((nnear + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J, JE - J,
                          nT, Tw, linv, h->status, 0, 0, 1, ncolb);
       (void)hipStreamWaitEvent(side, ev_steps, 0);
+      // both updates become runnable the moment the previous far update ends; started together, the far update's
+      // workgroups take CUs before all of the near update's (a tenth as many) are placed, and the near update -- which
+      // the next super-panel's steps wait for -- runs two rounds of 64x64 blocks instead of one (kernel trace: 118
+      // against 57 us).  A head start of a few microseconds lets the dispatcher place the near update first.
+      const int pause_ticks = getenv("PSBA_CHOL_FAR_PAUSE") ? atoi(getenv("PSBA_CHOL_FAR_PAUSE")) : 300;  // 3 us (sweep 0 / 1 / 100 / 300 / 600 / 1000 / 2000 ticks: 15.45 / 15.17 / 15.03 / 14.95-15.02 / 14.95 / 15.00 / 15.00 ms at n = 12 000)
+      if (pause_ticks > 0 && ev_far_prev) hipLaunchKernelGGL(k_cholg_pause, dim3(1), dim3(64), 0, side, (long long)pause_ticks);
       const int Tw2 = Tw + 4 * ncolb;
       if (Tw2 < nT - 1) {
         const long long MR2 = (nT - 1 - Tw2 + 3) / 4;
