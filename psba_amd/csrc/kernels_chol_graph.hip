@@ -306,8 +306,10 @@ __global__ __launch_bounds__(256) void k_cholg_update_cols(double *Lw, double *L
 // columns >= Tw.  Waves own 32x32 blocks (macro tiles, 2x2 MFMA tiles: each operand piece is used
 // twice) of the lower triangle in units of 32 rows, then single tiles of the e_a tile row.
 // Workgroup 0: the next diagonal block, then its factorization.
+// ncolb > 0: only the first ncolb macro columns (the look-ahead chain's near update, see k_cholg_update_wide4's part 1,
+// in 32x32 pieces: a quarter of the latency of a 64x64 block -- taken when all its waves fit on the chip at once)
 __global__ __launch_bounds__(256) void k_cholg_update_wide(double *Lw, double *Lx, int ld, int J, int KW, int nT,
-                                                           int Tw, double *linv, int *status) {
+                                                           int Tw, double *linv, int *status, int ncolb) {
   __shared__ Factor32Lds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -325,20 +327,27 @@ __global__ __launch_bounds__(256) void k_cholg_update_wide(double *Lw, double *L
     return;
   }
   const long long MR = (nT - 1 - Tw) / 2;  // macro rows: 32-row blocks below / right of the super-panel
-  const long long ntri = MR * (MR + 1) / 2;
+  const long long ntri = ncolb > 0 ? MR * ncolb : MR * (MR + 1) / 2;
   long long idx = (long long)(blockIdx.x - 1) * 4 + wave + 1;  // macro index 0 = workgroup 0's block
   if (idx >= ntri) {
     // e_a tile row
     const long long e = idx - ntri;
-    if (e >= nT - 1 - Tw) return;
+    if (e >= nT - 1 - Tw || (ncolb > 0 && e >= 2 * ncolb)) return;
     const int TC = Tw + (int)e;
     store_c_tile(Lw, ld, nT - 1, TC, li, lk, update_tile_k(Lw, Lx, ld, J, KW, nT - 1, TC, li, lk));
     return;
   }
-  int m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-  while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
-  while ((long long)m * (m + 1) / 2 > idx) m--;
-  const int mc = (int)(idx - (long long)m * (m + 1) / 2);
+  int m, mc;
+  if (ncolb > 0) {
+    m = (int)(idx / ncolb);
+    mc = (int)(idx % ncolb);
+    if (mc > m) return;
+  } else {
+    m = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+    while ((long long)(m + 1) * (m + 2) / 2 <= idx) m++;
+    while ((long long)m * (m + 1) / 2 > idx) m--;
+    mc = (int)(idx - (long long)m * (m + 1) / 2);
+  }
   const int TR0 = Tw + 2 * m, TC0 = Tw + 2 * mc;
   const bool dg = m == mc;  // diagonal macro tile: its upper-right 16x16 tile is not part of the triangle
   d4 c00 = load_c_tile(Lw, ld, TR0, TC0, li, lk), c10 = load_c_tile(Lw, ld, TR0 + 1, TC0, li, lk);
@@ -1367,13 +1376,22 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
       const long long MR = (nT - 1 - Tw) / 2;
       const long long work = MR * (MR + 1) / 2 - 1 + (nT - 1 - Tw);  // macro tiles but the first, e_a tiles
       hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((work + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J,
-                         JE - J, nT, Tw, linv, h->status);
+                         JE - J, nT, Tw, linv, h->status, 0);
     } else if (look) {
       const int ncolb = NB / 64;
       const long long MR = (nT - 1 - Tw + 3) / 4;
       (void)hipEventRecord(ev_steps, s);
       if (ev_far_prev) (void)hipStreamWaitEvent(s, ev_far_prev, 0);  // its columns carry the previous update
       const long long nnear = MR * ncolb + (4 * ncolb < nT - 1 - Tw ? 4 * ncolb : nT - 1 - Tw);
+      // ... in 32x32 pieces once all of them fit on the chip's 1024 SIMDs together (the last quarter of the matrix: one
+      // round of 64x64 blocks is 57 us of latency in front of the next super-panel's steps, one of 32x32 pieces ~18)
+      const long long MRh = (nT - 1 - Tw) / 2, nnear2 = MRh * (2 * ncolb) - 1 + (4 * ncolb < nT - 1 - Tw ? 4 * ncolb : nT - 1 - Tw);
+      long long fine_max = 1000;
+      if (const char *e = getenv("PSBA_CHOL_NEAR_FINE_MAX")) fine_max = atoll(e);
+      if (nnear2 <= fine_max)
+        hipLaunchKernelGGL(k_cholg_update_wide, dim3(1 + (unsigned)((nnear2 + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J, JE - J,
+                           nT, Tw, linv, h->status, 2 * ncolb);
+      else
       hipLaunchKernelGGL(k_cholg_update_wide4, dim3(1 + (unsigned)((nnear + 3) / 4)), dim3(256), 0, s, Lw, Lx, ld, J, JE - J,
                          nT, Tw, linv, h->status, 0, 0, 1, ncolb);
       (void)hipStreamWaitEvent(side, ev_steps, 0);
