@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_cholg_trsm_block(const double *Lw, doub
 // then finishes and publishes X_k+1 before it turns to its other blocks.  Per column block the critical path is
 // 16 + 16 MFMAs and two LDS transposes; the other 1200 MFMAs run beside it on the other three SIMDs.
 template <int NBK>
-__global__ __launch_bounds__(256) void k_cholg_trsm_block4(const double *Lw, double *Lx, int ld, int J, int T_first,
+__global__ __launch_bounds__(256, NBK <= 12 ? 2 : 1) void k_cholg_trsm_block4(const double *Lw, double *Lx, int ld, int J, int T_first,
                                                            int nTall, const double *linv) {
   __shared__ double sA[4][16][XS];  // a wave's scratch: accumulator layout -> operand layout
   __shared__ double sX[2][16][XS];  // the published X_k (operand layout), by parity of k
@@ -739,11 +739,9 @@ __global__ __launch_bounds__(256) void k_cholg_trsm_block4(const double *Lw, dou
       }
     }
   }
-  // finish block k (mine, fully updated): X_k = C_k L_kk^-T, stored and published
-  auto finish = [&](int q, int k) {
+  // finish block k (mine, fully updated): X_k = C_k L_kk^-T, stored and published.  p, q8: the rows of L_kk^-1
+  auto finish = [&](int q, int k, const Row8 &p, const Row8 &q8) {
     const int j = J + GB * k;
-    const double *Li = linv + (size_t)(j / GB) * GB * GB;
-    const Row8 p = load_row8(Li + (size_t)li * GB + 8 * lk), q8 = load_row8(Li + (size_t)(16 + li) * GB + 8 * lk);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       sA[wave][lk + 4 * r][li] = cl[q][r];
@@ -766,14 +764,33 @@ __global__ __launch_bounds__(256) void k_cholg_trsm_block4(const double *Lw, dou
     }
     store_x_tile(Lx, ld, j, T, li, lk, xl, xr);
   };
-  // block k2 (mine) minus X_k L_k2,k^T
-  auto apply = [&](int q, int k2, int k, const Row8 &X) {
-    const double *Lkk = Lx + (size_t)(J + GB * k2) * ld + J + GB * k;  // L_D block (k2, k)
-    const Row8 b0 = load_row8(Lkk + (size_t)li * ld + 8 * lk), b1 = load_row8(Lkk + (size_t)(16 + li) * ld + 8 * lk);
-    cl[q] = update_mfma(cl[q], X, b0);
-    cr[q] = update_mfma(cr[q], X, b1);
+  auto linv_rows = [&](int k, Row8 &p, Row8 &q8) {
+    const double *Li = linv + (size_t)((J + GB * k) / GB) * GB * GB;
+    p = load_row8(Li + (size_t)li * GB + 8 * lk);
+    q8 = load_row8(Li + (size_t)(16 + li) * GB + 8 * lk);
   };
-  if (wave == 0) finish(0, 0);
+  // the operands of step k's updates -- the blocks L_D(k2, k) of my blocks k2 > k -- depend on nothing computed
+  // here: they are fetched a step ahead (behind the previous step's MFMAs, in front of the barrier), and so are
+  // the rows of L_k+1,k+1^-1 for the wave that finishes block k + 1.  Fetched where they are used, every one of the
+  // twelve steps waited for two round trips to the L2 (~35 us per launch; ~18 this way)
+  Row8 B0[NQ], B1[NQ], P, Q;
+  auto fetch_step = [&](int k) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int k2 = 4 * q + wave;
+      if (k2 > k && k2 < NBK) {
+        const double *Lkk = Lx + (size_t)(J + GB * k2) * ld + J + GB * k;  // L_D block (k2, k)
+        B0[q] = load_row8(Lkk + (size_t)li * ld + 8 * lk);
+        B1[q] = load_row8(Lkk + (size_t)(16 + li) * ld + 8 * lk);
+      }
+    }
+    if (k + 1 < NBK && ((k + 1) & 3) == wave) linv_rows(k + 1, P, Q);
+  };
+  if (wave == 0) {
+    linv_rows(0, P, Q);
+    finish(0, 0, P, Q);
+  }
+  fetch_step(0);
 #pragma unroll
   for (int k = 0; k < NBK; k++) {
     __syncthreads();  // X_k is published (and everybody is done with the buffer X_k+1 will take)
@@ -784,10 +801,13 @@ __global__ __launch_bounds__(256) void k_cholg_trsm_block4(const double *Lw, dou
     for (int q = 0; q < NQ; q++) {
       const int k2 = 4 * q + wave;
       if (k2 > k && k2 < NBK) {
-        apply(q, k2, k, X);
-        if (k2 == k + 1) finish(q, k2);
+        cl[q] = update_mfma(cl[q], X, B0[q]);
+        cr[q] = update_mfma(cr[q], X, B1[q]);
+        if (k2 == k + 1) finish(q, k2, P, Q);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);  // (hoisted above the MFMAs, two operand sets are live at once: 270 registers)
+    if (k + 2 < NBK) fetch_step(k + 1);
   }
 }
 
