@@ -1527,7 +1527,10 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     const size_t need = 2 * (size_t)(n32 / c.NB + 2);
     while (look && h->chol_events.size() < need) {
       hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      // (no system-scope fence: producer and consumer are kernels on this device; a default event writes the L2 back
+      // on every record -- ~6 us in front of each near update with a factor's worth of dirty lines, kernel trace)
+      const unsigned flags = getenv("PSBA_CHOL_EVENT_SYSFENCE") ? hipEventDisableTiming : hipEventDisableTiming | hipEventDisableSystemFence;
+      if (hipEventCreateWithFlags(&e, flags) != hipSuccess) {
         look = false;
         break;
       }
