@@ -800,17 +800,25 @@ def test_backward_solve_variants(monkeypatch, one_wg):
 
 
 @pytest.mark.parametrize("n_cams", [130, 203])
-@pytest.mark.parametrize("lookahead", [False, True])
+@pytest.mark.parametrize("lookahead", [False, True, "onewave", "sysfence"])
 def test_two_level_blocked_panel_chain(monkeypatch, n_cams, lookahead):
     """PSBA_CHOL_BLOCKED=1 forces the chain large matrices take (super-panels of 128 columns:
     32-column steps that update the super-panel's own columns, one K = 128 update of the rest) at
     sizes the oracle solves quickly; 203 cameras end in a partial super-panel.  lookahead: round 4's split of
     that update (the next super-panel's columns first, the rest on a side stream beside the next super-panel's
-    steps: default from n32 = 6000, forced here with PSBA_CHOL_LOOKAHEAD=1)."""
+    steps: default from n32 = 6000, forced here with PSBA_CHOL_LOOKAHEAD=1; with it the block solve of the rows
+    below a super-panel -- four waves per tile row, or "onewave": PSBA_CHOL_TRSM_WAVE=1, the first form -- the near
+    update in 32x32 pieces and the pause in front of the far update; "sysfence": the chain's events as default
+    events)."""
     import psba_amd
     import psba_amd.synth as synth
     monkeypatch.setenv("PSBA_CHOL_BLOCKED", "1")
     monkeypatch.setenv("PSBA_CHOL_LOOKAHEAD", "1" if lookahead else "0")
+    if lookahead == "onewave":
+        monkeypatch.setenv("PSBA_CHOL_TRSM_WAVE", "1")
+    if lookahead == "sysfence":
+        monkeypatch.setenv("PSBA_CHOL_EVENT_SYSFENCE", "1")
+        monkeypatch.setenv("PSBA_CHOL_NEAR_FINE_MAX", "0")  # ... and the near update in 64x64 blocks
     if lookahead:  # ... and round 4's steps on the super-panel's diagonal block only + one block triangular solve
         monkeypatch.setenv("PSBA_CHOL_STEPS_DIAG_ONLY", "1")  # for the rows below (default from n32 = 8192)
     monkeypatch.setenv("PSBA_CHOL_UNFUSED", "1")  # (the two-level chain is a form of the unfused one: blocked = !fused && ...)
