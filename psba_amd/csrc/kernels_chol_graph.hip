@@ -1358,14 +1358,14 @@ static void enqueue_superpanel(psba_ctx *h, hipStream_t s, const ChainShape &c, 
   const int JE = J + NB < n32 ? J + NB : n32;  // end column of this super-panel
   // round 4: the steps factor the super-panel's own diagonal block only (tile rows < JE / 16), the rows below take
   // ONE block triangular solve (k_cholg_trsm_block).  PSBA_CHOL_STEPS_ALL_ROWS=1: every step on all rows, as before.
-  // Pays from ~8000 columns on (n = 12 000: 16.91 -> 16.53 ms per factorization); below, the steps are single fused
-  // launches of a few microseconds and the block solve's serial chain of MFMAs per tile row is the longer way
-  // (per factorization, all rows / diagonal only: n = 2040 835 / 1038 us, 2400 1027 / 1282, 3600 1794 / 2088,
-  // 6000 4276 / 4506).  PSBA_CHOL_STEPS_DIAG_ONLY=1 forces it (tests).
+  // With the one-wave block solve it paid from ~8000 columns on (n = 12 000: 16.91 -> 16.53 ms per factorization;
+  // all rows / diagonal only: n = 2040 835 / 1038 us, 2400 1027 / 1282, 3600 1794 / 2088, 6000 4276 / 4506); with
+  // four waves per tile row (k_cholg_trsm_block4) from ~4400: n = 3600 1760 / 1774 us, 4800 2712 / 2628, 6000
+  // 3781 / 3413, 7200 5326 / 4766, 8040 6636 / 6025.  PSBA_CHOL_STEPS_DIAG_ONLY=1 forces it (tests).
   const bool steps_all_rows = getenv("PSBA_CHOL_STEPS_ALL_ROWS") != nullptr;
   const bool steps_diag_forced = getenv("PSBA_CHOL_STEPS_DIAG_ONLY") != nullptr;
   const int nbk = (JE - J) / GB;
-  const bool diag_only = !steps_all_rows && (n32 >= 8192 || steps_diag_forced) && JE < n32 &&
+  const bool diag_only = !steps_all_rows && (n32 >= 4400 || steps_diag_forced) && JE < n32 &&
                          (nbk == 4 || nbk == 8 || nbk == 12 || nbk == 16);
   const int nTs = diag_only ? JE / 16 : nT;  // tile rows the steps see
   for (int j = J; j < JE; j += GB) {
@@ -1511,8 +1511,11 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
   // super-panel's ~12 small dependent launches (5 of the 17.6 ms of a 12 000 x 12 000 factorization were those
   // launches with the chip otherwise idle).  A far update follows the previous one on its stream and the
   // 32-column steps whose panel it applies (event); the near update waits for the previous far update, which
-  // wrote its columns.  PSBA_CHOL_LOOKAHEAD=0 / 1 forces it off / on (default: n32 >= 6000, wide4 kernel).
-  bool look = blocked && n32 >= 6000 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
+  // wrote its columns.  PSBA_CHOL_LOOKAHEAD=0 / 1 forces it off / on (default: on; n32 >= 6000 until the end of round 4).
+  // (with the pause, the fine near update and the fence-free events it pays wherever the blocked chain runs: per
+  // factorization off / on, n = 1860 777 / 731 us, 2520 1070 / 1032, 3000 1333 / 1282, 4200 2204 / 2106, 5100 2938 /
+  // 2596, 6000 3949 / 3410, 7200 5515 / 4808)
+  bool look = blocked && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
   if (const char *e = getenv("PSBA_CHOL_LOOKAHEAD")) look = blocked && atoi(e) != 0 && c.NB % 64 == 0 && !getenv("PSBA_CHOL_WIDE2");
   if (look) {
     if (!h->chol_side) {
@@ -1527,9 +1530,12 @@ static void enqueue_chain(psba_ctx *h, hipStream_t s, bool skip_diag) {
     const size_t need = 2 * (size_t)(n32 / c.NB + 2);
     while (look && h->chol_events.size() < need) {
       hipEvent_t e;
-      // (no system-scope fence: producer and consumer are kernels on this device; a default event writes the L2 back
-      // on every record -- ~6 us in front of each near update with a factor's worth of dirty lines, kernel trace)
-      const unsigned flags = getenv("PSBA_CHOL_EVENT_SYSFENCE") ? hipEventDisableTiming : hipEventDisableTiming | hipEventDisableSystemFence;
+      // a device-scope release when the event is recorded (hipEventReleaseToDevice): producer and consumer are kernels
+      // of this device.  A default event writes the L2 back at system scope on every record (~6 us in front of each
+      // near update with a factor's worth of dirty lines, kernel trace).  hipEventDisableSystemFence, no fence at
+      // all, was 0.15 ms faster per 12 000 x 12 000 factorization and is documented for timing events only: one LM run
+      // in about forty ended on a different cost with it -- not used.  PSBA_CHOL_EVENT_SYSFENCE=1: default events.
+      const unsigned flags = getenv("PSBA_CHOL_EVENT_SYSFENCE") ? hipEventDisableTiming : hipEventDisableTiming | hipEventReleaseToDevice;
       if (hipEventCreateWithFlags(&e, flags) != hipSuccess) {
         look = false;
         break;
