@@ -249,7 +249,11 @@ int psba_set_step(psba_handle h, const double *dp);
  * lambda = |sum_i E_i| / (6 nCams) with E = diag(L L^T) - diag(S).  info3 (may be NULL) =
  * (delta, beta, number of block columns that took the one-column route).  reassemble = 0 skips
  * the assembly and factors what the reduce buffer holds (psba_schur_assemble or
- * psba_set_reduce_buffer before it): the hook the tests use to factor a chosen matrix. */
+ * psba_set_reduce_buffer before it): the hook the tests use to factor a chosen matrix.
+ * PSBA_SOLVER_PCG (no dense S, and the reference has no sparse mode): lambda is the Gershgorin shift of the
+ * stored blocks instead, max(0, -min_i (S_ii - sum_{c != i} |S_ic|)) -- the smallest shift that makes S + lambda I
+ * diagonally dominant -- or 1e-6 max_i of those margins when S is diagonally dominant already;
+ * info3 = (min margin, max margin, 0). */
 int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *info3);
 
 typedef struct {

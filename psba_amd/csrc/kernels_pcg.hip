@@ -13,6 +13,7 @@
 //     positive definite reports PSBA_NOT_SPD like the dense factorization does, so the LM loop's
 //     damping protocol is unchanged.
 #include <cstdlib>
+#include <vector>
 
 #include "psba_internal.h"
 
@@ -175,6 +176,46 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double *val, const int *
   block_sum_to(pq, pc + PC_PQ + PC_NPQ * (it & 3) + (blockIdx.x & (PC_NPQ - 1)));
 }
 
+// Gershgorin margins of the stored S: d[6 j + r] = S_rr - sum_{c != r} |S_rc| over camera j's block row (the same
+// walk as k_pcg_spmv).  min d > 0 proves S positive definite; -min d is a shift that makes S + lambda I diagonally
+// dominant -- the damping estimate of the trust-region loop in the block-sparse mode, where the reference's modified
+// Cholesky (PSBA/cl_cholmod.cpp:25-107, a dense factorization) has nothing to factor.
+__global__ __launch_bounds__(256) void k_bsr_gershgorin(const double *val, const int *rowptr, const int2 *rowent, int nC,
+                                                        double *d) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double off = 0.0, diag = 0.0;
+  const int g = lane / 6, r = lane % 6;
+  if (j < nC && g < 8) {
+    const int e1 = rowptr[j + 1];
+    for (int e = rowptr[j] + g; e < e1; e += 8) {
+      const int2 en = rowent[e];
+      const int how = en.y >> 28;
+      const double *B = val + 36 * (size_t)en.x;
+      if (how == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) off += fabs(B[6 * r + c]);
+      } else if (how == 1) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) off += fabs(B[6 * c + r]);
+      } else {  // the diagonal block, read through its lower triangle
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double v = c <= r ? B[6 * r + c] : B[6 * c + r];
+          if (c == r) diag += v; else off += fabs(v);
+        }
+      }
+    }
+  }
+  off += __shfl_down(off, 24, 64);
+  off += __shfl_down(off, 12, 64);
+  off += __shfl_down(off, 6, 64);
+  diag += __shfl_down(diag, 24, 64);
+  diag += __shfl_down(diag, 12, 64);
+  diag += __shfl_down(diag, 6, 64);
+  if (j < nC && lane < 6) d[6 * (size_t)j + lane] = diag - off;
+}
+
 // start: x = 0, r = b, z = M^-1 r, p = z, q = 0, r.z into slot 0, b.b; one thread per unknown
 __global__ __launch_bounds__(256) void k_pcg_start(const double *b, const double *minv, double *x, double *r, double *z,
                                                    double *p, double *q, int n, double *pc) {
@@ -273,6 +314,33 @@ int launch_bsr_finalize(psba_ctx *h, double mu) {
   hipLaunchKernelGGL(k_bsr_finalize, dim3((42 * nC + 255) / 256), dim3(256), 0, h->stream, h->bs_val, h->bs_diag, h->bs_ea, h->U,
                      h->ga, h->rank == 0 ? mu : 0.0, nC, h->scal, h->status, h->try_id);
   PSBA_HIP(h, hipGetLastError());
+  return PSBA_OK;
+}
+
+// lambda = max(0, -min_i d_i) of the stored S (k_bsr_gershgorin), a small positive value when S is diagonally
+// dominant although the solve failed (rounding); info3 = { min d, max S_ii, 0 }
+int launch_bsr_gershgorin(psba_ctx *h, double *lambda, double *info3) {
+  const int n = h->d.nA, nC = h->d.nC;
+  double *d = h->pcg_vec + 3 * (size_t)n;  // (the solve's q: free between solves)
+  hipLaunchKernelGGL(k_bsr_gershgorin, dim3((nC + 3) / 4), dim3(256), 0, h->stream, h->bs_val, h->bs_rowptr, h->bs_rowent, nC, d);
+  PSBA_HIP(h, hipGetLastError());
+  std::vector<double> hd((size_t)n);
+  PSBA_HIP(h, hipMemcpyAsync(hd.data(), d, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  double dmin = hd[0];
+  for (int i = 1; i < n; i++) dmin = hd[i] < dmin ? hd[i] : dmin;
+  // max S_ii >= max (d_i): a scale for the fallback
+  double dmax = 0.0;
+  for (int i = 0; i < n; i++) dmax = hd[i] > dmax ? hd[i] : dmax;
+  double lam = dmin < 0.0 ? -dmin : 0.0;
+  if (!(lam > 0.0)) lam = dmax > 0.0 ? 1e-6 * dmax : 1.0;
+  if (!(lam == lam)) lam = 1.0;  // (NaN in S: the loop's own guard ends it)
+  *lambda = lam;
+  if (info3) {
+    info3[0] = dmin;
+    info3[1] = dmax;
+    info3[2] = 0.0;
+  }
   return PSBA_OK;
 }
 

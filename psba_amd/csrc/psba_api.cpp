@@ -1178,7 +1178,20 @@ int psba_cholmod_lambda(psba_handle h, int reassemble, double *lambda, double *i
   NEED(h, h->uploaded, "no problem uploaded");
   if (h->nranks > 1 && !h->comm)
     return fail(h, PSBA_E_INVALID, "psba_cholmod_lambda on a rank layout needs the communicator (S must be complete)");
-  NEED(h, h->solver != PSBA_SOLVER_PCG, "the modified Cholesky needs the dense S: PSBA_SOLVER_DENSE");
+  if (h->solver == PSBA_SOLVER_PCG) {
+    // block-sparse mode: no dense S to factor -- the damping estimate is the Gershgorin shift of the stored blocks
+    // (kernels_pcg.hip; no reference counterpart: the reference has no sparse mode)
+    NEED(h, h->linearized, "psba_linearize first");
+    if (reassemble || !h->assembled) {
+      TRY(launch_schur(h, 0.0, false));
+      TRY(allreduce_schur(h));  // every rank then looks at the same complete blocks
+    }
+    double lam = 0.0;
+    TRY(launch_bsr_gershgorin(h, &lam, info3));
+    if (lambda) *lambda = lam;
+    h->assembled = h->solved = false;
+    return PSBA_OK;
+  }
   if (reassemble) {
     // S at lambda = 0 again (the failed factorization worked in place), then the modified
     // Cholesky on a copy of it (trust_region.cpp:341-363)

@@ -367,6 +367,7 @@ int launch_backsub_fk(psba_ctx *h, double mu);
 // kernels_pcg.hip
 int launch_bsr_finalize(psba_ctx *h, double mu);
 int launch_pcg_solve(psba_ctx *h);
+int launch_bsr_gershgorin(psba_ctx *h, double *lambda, double *info3);
 // kernels_chol_graph.hip
 int launch_chol_graph(psba_ctx *h);
 int chol_dist_shape(psba_ctx *h, int *NB, int *blocked);

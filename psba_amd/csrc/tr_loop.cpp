@@ -142,11 +142,28 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
       psba_try_scalars sc;
       TR_TRY(psba_schur_assemble(h, lambda));
       TR_TRY(psba_schur_reduce(h));
-      TR_TRY(psba_schur_solve(h));
+      const int solve_rc = psba_schur_solve(h);
+      if (solve_rc < 0) return solve_rc;
+      // block-sparse mode at lambda = 0: the conjugate gradients do not stop at a singular S the way a factorization
+      // does (the gauge directions of an unanchored problem: a consistent semidefinite system), they crawl -- more
+      // iterations than unknowns, or none left -- and the step they return is rounding noise along those directions.
+      // That is this mode's "not positive definite": the loop then damps, as the reference does after its failed
+      // factorization (trust_region.cpp:341-363), starting from a damping at rounding level of the diagonal
+      bool weak = false;
+      if (h->solver == PSBA_SOLVER_PCG && lambda == 0.0) {
+        int it = 0;
+        double rr = 0;
+        TR_TRY(psba_pcg_info(h, &it, &rr, nullptr, nullptr));
+        weak = solve_rc == PSBA_PCG_MAXIT || it > (int)nA;
+      }
       TR_TRY(psba_backsub(h, lambda, &sc));
-      if (sc.status & PSBA_NOT_SPD) {
+      if ((sc.status & PSBA_NOT_SPD) || weak) {
         chol_fail++;
-        if (lambda == 0.0) {  // :341-363
+        if (lambda == 0.0 && weak && !(sc.status & PSBA_NOT_SPD)) {
+          double md = 0;
+          TR_TRY(psba_max_diag(h, &md));
+          lambda = 1e-8 * md;
+        } else if (lambda == 0.0) {  // :341-363
           TR_TRY(psba_cholmod_lambda(h, 1, &lambda, nullptr));
         } else {
           lambda = 2 * lambda;  // :365-368
