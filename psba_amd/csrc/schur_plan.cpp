@@ -40,11 +40,12 @@ namespace {
 inline long long tri(long long j) { return j * (j + 1) / 2; }
 constexpr int ROW = 16;       // lanes that go through the LDS together; bank pairs of a 64-bit access
 int DUPS = 1;                 // let a bank pair be used twice in a row once the window is full
-int WINDOW = 3;               // open rows while dealing: more rows fill better but spread a point's
+int WINDOW = 2;               // open rows while dealing: more rows fill better but spread a point's
                               // products over more waves, i.e. more cache lines per load instruction
                               // (measured on venice-shaped, scripts/k2_window_sweep.sh: strict rows
                               // 80 / 59 / 52 / 50 / 49 us at 1 / 2 / 3 / 4 / 8; with one repeat allowed
-                              // 52 / 42 / 42 / 42 / 46 us)
+                              // 52 / 42 / 42 / 42 / 46 us; end of round 4, A/B on three boxes, assembly + reduce
+                              // by HIP events at 2 / 3 / 4 / 6: 48.1-48.4 / 49.0-49.6 / 50.3 / 53.2 -- 2 since then)
 }  // namespace
 
 int build_schur_plan(psba_ctx *h, int nCams, int nPts, int nObs, const int *iidx, const int *jidx,
