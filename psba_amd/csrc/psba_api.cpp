@@ -90,6 +90,13 @@ ProfScope::~ProfScope() {
 template <typename T>
 static int dev_alloc(psba_ctx *h, T **p, size_t n) {
   PSBA_HIP(h, hipMalloc((void **)p, sizeof(T) * (n ? n : 1)));
+  // PSBA_DEBUG_POISON=1 (tests): fresh allocations filled with 0xFF bytes (NaN as doubles, -1 as ints), so that
+  // anything read before it is written shows in the results instead of depending on what the allocator recycled
+  static const bool poison = getenv("PSBA_DEBUG_POISON") != nullptr;
+  if (poison) {
+    PSBA_HIP(h, hipMemsetAsync(*p, 0xFF, sizeof(T) * (n ? n : 1), h->stream));
+    PSBA_HIP(h, hipStreamSynchronize(h->stream));
+  }
   return PSBA_OK;
 }
 template <typename T>
@@ -222,7 +229,11 @@ int psba_create(int device, psba_handle *out) {
   // the status stamps live in the tail of the scalar block so that one copy fetches both
   h->status = reinterpret_cast<int *>(h->scal + 8);
   h->h_status = reinterpret_cast<int *>(h->h_scal + 8);
-  (void)hipMemset(h->scal, 0, sizeof(double) * NSCAL);
+  // (on the handle's stream and waited for: hipMemset on the null stream is asynchronous to the host for device
+  // memory and a non-blocking stream does not wait for the null stream -- a late memset would wipe the status
+  // stamps and the partial sums of a try already running)
+  (void)hipMemsetAsync(h->scal, 0, sizeof(double) * NSCAL, h->stream);
+  (void)hipStreamSynchronize(h->stream);
   h->h_scal[NSCAL] = 0.0;  // the publish stamp (psba_backsub_wait)
   *out = h;
   return PSBA_OK;
@@ -589,7 +600,7 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
       h->packed_doubles = h->packedN;  // 36 doubles per block of the lower block triangle, canonical order
       TRY(dev_alloc(h, &h->redp, h->packed_doubles));
       TRY(dev_alloc(h, &h->diag0, (size_t)21 * 36));
-      PSBA_HIP(h, hipMemset(h->diag0, 0, sizeof(double) * 21 * 36));
+      PSBA_HIP(h, hipMemsetAsync(h->diag0, 0, sizeof(double) * 21 * 36, h->stream));
       if (getenv("PSBA_SCHUR_PLAN_INFO"))
         fprintf(stderr, "[psba] K2 plan%s: %d groups, %d workgroups, %lld products in %zu item slots (fill %.3f), slabs %.1f MB\n",
                 plan.runs ? " (runs layout)" : "", h->nGroups, h->nWg, plan.real_items, plan.items.size(),
@@ -643,6 +654,9 @@ int psba_upload_problem(psba_handle h, int nCams, int n3Dpts, int n2Dprojs, cons
   PSBA_HIP(h, hipMemcpy(h->tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice));
   PSBA_HIP(h, hipMemsetAsync(h->dp, 0, sizeof(double) * d.nT, h->stream));
   PSBA_HIP(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
+  // ... and the blocking copies above went through the null stream, which this handle's non-blocking stream does
+  // not wait for: everything on the device is done before the first kernel can be queued
+  PSBA_HIP(h, hipDeviceSynchronize());
   h->uploaded = true;
   return PSBA_OK;
 }
