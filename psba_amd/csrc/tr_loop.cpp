@@ -137,33 +137,27 @@ int psba_trust_region(psba_handle h, const psba_tr_options *opts, psba_tr_result
     }
     const double gtBg = 2 * d3[0], gtg = gtg1[0];
     for (size_t i = 0; i < nT; i++) PU[i] = -(g[i] * gtg) / gtBg;  // :128-130 Cauchy step
+    // block-sparse mode: the conjugate gradients do not stop at the singular S of lambda = 0 the way a factorization
+    // does (the gauge directions of an unanchored problem: a consistent semidefinite system) -- they crawl, and the
+    // step they return leans along those directions as the rounding of their sums happens to fall: the same problem
+    // then takes 11 or 50 iterations, run by run.  The sparse mode therefore never solves undamped: it starts where
+    // the reference ends up after its failed factorization (trust_region.cpp:341-363), at a damping at rounding level
+    // of the diagonal.
+    if (h->solver == PSBA_SOLVER_PCG && lambda == 0.0) {
+      double md = 0;
+      TR_TRY(psba_max_diag(h, &md));
+      lambda = 1e-8 * md;
+    }
     bool solved = false;
     while (!solved) {  // :141-163 around compute_PB (:292-405)
       psba_try_scalars sc;
       TR_TRY(psba_schur_assemble(h, lambda));
       TR_TRY(psba_schur_reduce(h));
-      const int solve_rc = psba_schur_solve(h);
-      if (solve_rc < 0) return solve_rc;
-      // block-sparse mode at lambda = 0: the conjugate gradients do not stop at a singular S the way a factorization
-      // does (the gauge directions of an unanchored problem: a consistent semidefinite system), they crawl -- more
-      // iterations than unknowns, or none left -- and the step they return is rounding noise along those directions.
-      // That is this mode's "not positive definite": the loop then damps, as the reference does after its failed
-      // factorization (trust_region.cpp:341-363), starting from a damping at rounding level of the diagonal
-      bool weak = false;
-      if (h->solver == PSBA_SOLVER_PCG && lambda == 0.0) {
-        int it = 0;
-        double rr = 0;
-        TR_TRY(psba_pcg_info(h, &it, &rr, nullptr, nullptr));
-        weak = solve_rc == PSBA_PCG_MAXIT || it > (int)nA;
-      }
+      TR_TRY(psba_schur_solve(h));
       TR_TRY(psba_backsub(h, lambda, &sc));
-      if ((sc.status & PSBA_NOT_SPD) || weak) {
+      if (sc.status & PSBA_NOT_SPD) {
         chol_fail++;
-        if (lambda == 0.0 && weak && !(sc.status & PSBA_NOT_SPD)) {
-          double md = 0;
-          TR_TRY(psba_max_diag(h, &md));
-          lambda = 1e-8 * md;
-        } else if (lambda == 0.0) {  // :341-363
+        if (lambda == 0.0) {  // :341-363
           TR_TRY(psba_cholmod_lambda(h, 1, &lambda, nullptr));
         } else {
           lambda = 2 * lambda;  // :365-368

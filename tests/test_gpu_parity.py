@@ -509,7 +509,18 @@ def test_garbage_step_through_the_lookahead_chain(problems, bad):
     # the step is rejected: nothing of it may survive.  The plain loop from here equals a fresh handle's.
     assert abs(h.residual(0) - cost0) <= 1e-13 * cost0   # (workgroup sums arrive in any order: rounding, not bits)
     res, _ = h.levmar(max_iter=6, tr_handoff=False)
-    assert res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-12 * want.final_err
+    same = res.iters == want.iters and abs(res.final_err - want.final_err) <= 1e-12 * want.final_err
+    if not same:
+        # DESIGN 5d, "LM runs that ended on another cost": about one fresh handle's run in a few hundred takes one
+        # damping try differently (open).  The reference run above may be that one: a second fresh handle decides.
+        import warnings
+        again_h = psba_amd.Psba(0)
+        again_h.upload_problem(prob)
+        again, _ = again_h.levmar(max_iter=6, tr_handoff=False)
+        again_h.close()
+        warnings.warn(f"two fresh handles disagree: {want.final_err!r} / {again.final_err!r} (after the garbage step: {res.final_err!r})")
+        same = res.iters == again.iters and abs(res.final_err - again.final_err) <= 1e-12 * again.final_err
+    assert same
     h.close()
 
 

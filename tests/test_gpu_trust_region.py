@@ -220,14 +220,13 @@ def test_sparse_mode_damping_estimate(problems):
     h.close()
 
 
-@pytest.mark.parametrize("name", ["54cams"])
+@pytest.mark.parametrize("name", ["7cams", "54cams"])
 def test_solve_alternates_in_sparse_mode(name, golden, problems):
-    """psba_solve (LM <-> TR, PSBA/main.cpp:193-208) on the block-sparse S + conjugate gradients: both loops run --
-    at lambda = 0 the trust-region loop reads conjugate gradients that crawl (more iterations than unknowns) as
-    its failed factorization and damps from rounding level of the diagonal -- and the run ends where the dense
-    mode's does.  (The 7- and 9-camera problems, 42 / 54 unknowns with the gauge free, are not in the list: there
-    the sparse alternation reaches the dense optimum in some runs and stalls above it in others within 50
-    iterations -- DESIGN section 7.)"""
+    """psba_solve (LM <-> TR, PSBA/main.cpp:193-208) on the block-sparse S + conjugate gradients: both loops run and
+    the run ends where the dense mode's does.  The sparse trust-region loop never solves undamped (the conjugate
+    gradients crawl on the gauge-singular S of lambda = 0 and the step then depends on the rounding of their sums:
+    11 to 50 iterations for the same problem, run by run, before this was so); it starts at 1e-8 of the largest
+    diagonal entry, where the reference ends up after its failed factorization."""
     import psba_amd
     prob = problems[name]
     ref = psba_amd.Psba(0)
@@ -239,7 +238,8 @@ def test_solve_alternates_in_sparse_mode(name, golden, problems):
     h.upload_problem(prob)
     res = h.solve(max_iter=50)
     assert res.lm_calls >= 1 and res.tr_calls >= 1 and res.iters <= 50
-    assert res.final_err <= 1.05 * golden["problems"][name]["final_err"]
+    if name in golden["problems"]:
+        assert res.final_err <= 1.05 * golden["problems"][name]["final_err"]
     assert abs(res.final_err - want.final_err) <= 2e-2 * want.final_err
     cams, pts = h.get_params()
     ex = Oracle(prob).exQT(cams=cams, pts=pts)
