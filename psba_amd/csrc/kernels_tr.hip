@@ -13,6 +13,12 @@
 //               CL_files/cholmod_blk.cl:87-846) as ONE workgroup walking the block columns --
 //               the reference chains ~nA device-enqueued launches of 3x3 work-groups.  It only
 //               runs when S is not positive definite at lambda = 0 (trust_region.cpp:341-363).
+//   k_cholmod_grid  the same walk by a cooperative grid (one thread per row of the block column,
+//               grid-wide barriers where the one workgroup has its own) for large S: every sum is
+//               formed by one thread in the same order as in k_cholmod, so the factor is the same
+//               bit for bit.
+#include <hip/hip_cooperative_groups.h>
+
 #include "camera_model.h"
 #include "psba_internal.h"
 
@@ -282,6 +288,192 @@ __global__ __launch_bounds__(CM_THREADS) void k_cholmod(double *M, int ld, int n
   }
 }
 
+// The same algorithm on a cooperative grid.  What the one workgroup shares through LDS is here
+// either recomputed by every thread from a nine-double block in global memory (the 3 x 3 factor:
+// same arithmetic, same result everywhere, no broadcast) or kept in per-step slots that are zeroed
+// once before the launch and never reset (the "above beta" flags and the column maxima: a slot
+// per block column / column, so no workgroup can read a slot that another already reuses).
+// gs: [0..9) T_JJ | ov[nJ] ints | ov1[n] ints | th[n] u64 | part[gridDim.x] doubles (host layout below).
+constexpr int CMG_THREADS = 128;
+
+__global__ __launch_bounds__(CMG_THREADS) void k_cholmod_grid(double *M, int ld, int n, double *aux, double *out,
+                                                              double *gs) {
+  namespace cg = cooperative_groups;
+  cg::grid_group grid = cg::this_grid();
+  __shared__ double sRed[CMG_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int gtid = blockIdx.x * CMG_THREADS + tid, GT = gridDim.x * CMG_THREADS;
+  const int nJ = n / 3;
+  double *C = aux, *bak = aux + n, *dg = aux + 4 * (size_t)n;
+  volatile double *T = gs;
+  int *ov = reinterpret_cast<int *>(gs + 10);                       // [nJ + 1]
+  int *ov1 = ov + (nJ + 2);                                          // [n]
+  unsigned long long *th = reinterpret_cast<unsigned long long *>(gs + 10 + (nJ + 2 + n + 1) / 2 + 1);  // [n + 2]
+  double *part = reinterpret_cast<double *>(th + n + 2);            // [gridDim.x]
+  auto wave_max = [](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+  };
+  auto bits = [](double v) { return (unsigned long long)__double_as_longlong(v); };
+  auto peek = [](unsigned long long *p) { return __longlong_as_double((long long)*(volatile unsigned long long *)p); };
+  // delta, beta (cl_cholmod.cpp:109-168, cholmod_blk.cl:796-825); th[n], th[n + 1] hold xi, gamma
+  {
+    double xi = 0.0, gamma = 0.0;
+    for (int r = gtid; r < n; r += GT) {
+      const double *row = M + (size_t)r * ld;
+      for (int c = 0; c < n; c++) {
+        const double v = fabs(row[c]);
+        if (c == r)
+          gamma = fmax(gamma, v);
+        else
+          xi = fmax(xi, v);
+      }
+      dg[r] = row[r];
+    }
+    xi = wave_max(xi);
+    gamma = wave_max(gamma);
+    if ((tid & 63) == 0) {
+      atomicMax(th + n, bits(xi));
+      atomicMax(th + n + 1, bits(gamma));
+    }
+  }
+  grid.sync();
+  const double xi = peek(th + n), gamma = peek(th + n + 1);
+  const double delta = 1e-15 * fmax(xi + gamma, 1.0);
+  const double beta = sqrt(fmax(fmax(gamma, 1e-15), xi / sqrt((double)n * n - 1.0)));
+  int single = 0;
+  for (int J = 0; J + 3 <= n; J += 3) {
+    for (int r = J + gtid; r < n; r += GT)
+#pragma unroll
+      for (int c = 0; c < 3; c++) bak[3 * (size_t)r + c] = M[(size_t)r * ld + J + c];
+    if (blockIdx.x == 0 && tid < 9) {
+      const int u = tid / 3, v = tid % 3;
+      double t = M[(size_t)(J + u) * ld + J + v];
+      for (int k = 0; k < J; k++) t -= M[(size_t)(J + u) * ld + k] * M[(size_t)(J + v) * ld + k];
+      T[tid] = t;
+    }
+    grid.sync();  // T_JJ is there (and nobody reads the previous one any more: those reads sit before the
+                  // previous step's second barrier)
+    // L_JJ L_JJ^T = T_JJ (:134-205), by every thread
+    int fail = 0;
+    double l00 = T[0], l10 = 0, l11 = 0, l20 = 0, l21 = 0, l22 = 0;
+    {
+      const double t3 = T[3], t4 = T[4], t6 = T[6], t7 = T[7], t8 = T[8];
+      if (!isfinite(l00) || l00 <= 0) fail = 1;
+      if (!fail) {
+        l00 = sqrt(l00);
+        l10 = t3 / l00;
+        l20 = t6 / l00;
+        l11 = t4 - l10 * l10;
+        if (!isfinite(l11) || l11 <= 0) fail = 1;
+      }
+      if (!fail) {
+        l11 = sqrt(l11);
+        l21 = (t7 - l20 * l10) / l11;
+        l22 = t8 - l20 * l20 - l21 * l21;
+        if (!isfinite(l22) || l22 <= 0 || !isfinite(l10) || !isfinite(l20) || !isfinite(l21)) fail = 1;
+      }
+      if (!fail) l22 = sqrt(l22);
+    }
+    if (!fail) {  // (uniform over the grid: every thread factored the same nine numbers)
+      int over = 0;
+      for (int i = J + 3 + gtid; i < n; i += GT) {
+        double t0 = M[(size_t)i * ld + J], t1 = M[(size_t)i * ld + J + 1], t2 = M[(size_t)i * ld + J + 2];
+        const double *Li = M + (size_t)i * ld, *L0 = M + (size_t)J * ld, *L1 = L0 + ld, *L2 = L1 + ld;
+        for (int k = 0; k < J; k++) {
+          const double lik = Li[k];
+          t0 -= lik * L0[k];
+          t1 -= lik * L1[k];
+          t2 -= lik * L2[k];
+        }
+        const double x0 = t0 / l00;
+        const double x1 = (t1 - x0 * l10) / l11;
+        const double x2 = (t2 - x0 * l20 - x1 * l21) / l22;
+        M[(size_t)i * ld + J] = x0;
+        M[(size_t)i * ld + J + 1] = x1;
+        M[(size_t)i * ld + J + 2] = x2;
+        if (x0 > beta || x1 > beta || x2 > beta) over = 1;
+      }
+      if (over) atomicOr(ov + J / 3, 1);
+      grid.sync();
+      if (!*(volatile int *)(ov + J / 3)) {
+        if (gtid == 0) {
+          double *d0 = M + (size_t)J * ld + J;
+          d0[0] = l00; d0[1] = 0; d0[2] = 0;
+          d0[ld] = l10; d0[ld + 1] = l11; d0[ld + 2] = 0;
+          d0[2 * (size_t)ld] = l20; d0[2 * (size_t)ld + 1] = l21; d0[2 * (size_t)ld + 2] = l22;
+        }
+        for (int i = J + 3 + gtid; i < n; i += GT)
+#pragma unroll
+          for (int v = 0; v < 3; v++) M[(size_t)(J + v) * ld + i] = 0.0;
+        continue;  // (what this step wrote last is read by no later step, only by the sums of E behind a barrier)
+      }
+    }
+    // restore the block column and take its columns one at a time (:240-262, :436-462, steps :560-706)
+    single++;
+    for (int r = J + gtid; r < n; r += GT)
+#pragma unroll
+      for (int c = 0; c < 3; c++) M[(size_t)r * ld + J + c] = bak[3 * (size_t)r + c];
+    grid.sync();
+    for (int c = 0; c < 3; c++) {
+      const int j = J + c;
+      double d = M[(size_t)j * ld + j];  // (by every thread: the same sum everywhere)
+      for (int k = 0; k < j; k++) d -= M[(size_t)j * ld + k] * M[(size_t)j * ld + k];
+      d = fmax(fabs(d), delta);
+      double ljj = sqrt(d);
+      int over = 0;
+      double theta = 0.0;
+      for (int i = j + 1 + gtid; i < n; i += GT) {
+        double cij = M[(size_t)i * ld + j];
+        for (int k = 0; k < j; k++) cij -= M[(size_t)i * ld + k] * M[(size_t)j * ld + k];
+        C[i] = cij;
+        const double l = cij / ljj;
+        M[(size_t)i * ld + j] = l;
+        M[(size_t)j * ld + i] = 0.0;
+        if (l > beta) over = 1;  // :641 compares without fabs
+        theta = fmax(theta, fabs(cij));
+      }
+      if (over) atomicOr(ov1 + j, 1);
+      theta = wave_max(theta);
+      if ((tid & 63) == 0 && theta > 0.0) atomicMax(th + j, bits(theta));
+      grid.sync();
+      if (*(volatile int *)(ov1 + j)) {
+        ljj = peek(th + j) / beta;  // :673-674
+        for (int i = j + 1 + gtid; i < n; i += GT) M[(size_t)i * ld + j] = C[i] / ljj;
+      }
+      if (gtid == 0) M[(size_t)j * ld + j] = ljj;
+      grid.sync();
+    }
+  }
+  grid.sync();
+  // E_i = sum_k L_ik^2 - A_ii (kern_cholmod_E, :830-846); lambda = |sum E| / n (trust_region.cpp:355-362)
+  double e = 0.0;
+  for (int i = gtid; i < n; i += GT) {
+    double s = 0.0;
+    for (int k = 0; k <= i; k++) s += M[(size_t)i * ld + k] * M[(size_t)i * ld + k];
+    e += s - dg[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+  if ((tid & 63) == 0) sRed[tid >> 6] = e;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < CMG_THREADS / 64; w++) s += sRed[w];
+    part[blockIdx.x] = s;
+  }
+  grid.sync();
+  if (gtid == 0) {
+    double s = 0.0;
+    for (unsigned b = 0; b < gridDim.x; b++) s += ((volatile double *)part)[b];
+    out[0] = fabs(s) / n;
+    out[1] = delta;
+    out[2] = beta;
+    out[3] = (double)single;
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------
 int launch_jmul(psba_ctx *h, const double *x1_dev, const double *x2_dev, double *out1_dev, double *dots_dev) {
   JmulArgs a;
@@ -328,6 +520,23 @@ int launch_cholmod(psba_ctx *h, double *out4_dev) {
   double *M = h->chol_L, *aux = h->chol_L + (size_t)(h->n32 + 1) * ld;  // 5 n <= (n32 + 15) * n32 doubles of room
   if ((size_t)5 * n > (size_t)(h->n32 + 15) * ld) return fail(h, PSBA_E_INVALID, "cholmod scratch too small");
   PSBA_HIP(h, hipMemcpyAsync(M, h->red, sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, h->stream));
+  // large S: the cooperative grid (one workgroup needs minutes at n = 12 000); PSBA_CHOLMOD_GRID=1 / 0 forces
+  // either (the tests run the small problems through both and compare)
+  const char *force = getenv("PSBA_CHOLMOD_GRID");
+  const bool use_grid = force ? atoi(force) != 0 : n >= 1536;
+  if (use_grid) {
+    int nwg = (n + CMG_THREADS - 1) / CMG_THREADS;
+    if (nwg > 256) nwg = 256;  // one workgroup of 128 threads per CU at most: co-resident by a wide margin
+    const int nJ = n / 3;
+    double *gs = aux + 5 * (size_t)n;
+    const size_t gs_doubles = 10 + (size_t)(nJ + 2 + n + 1) / 2 + 1 + (n + 2) + nwg;
+    if ((size_t)5 * n + gs_doubles > (size_t)(h->n32 + 15) * ld) return fail(h, PSBA_E_INVALID, "cholmod scratch too small");
+    PSBA_HIP(h, hipMemsetAsync(gs, 0, sizeof(double) * gs_doubles, h->stream));
+    int ld_ = ld, n_ = n;
+    void *args[] = {&M, &ld_, &n_, &aux, &out4_dev, &gs};
+    PSBA_HIP(h, hipLaunchCooperativeKernel((const void *)k_cholmod_grid, dim3(nwg), dim3(CMG_THREADS), args, 0, h->stream));
+    return PSBA_OK;
+  }
   hipLaunchKernelGGL(k_cholmod, dim3(1), dim3(CM_THREADS), 0, h->stream, M, ld, n, aux, out4_dev);
   PSBA_HIP(h, hipGetLastError());
   return PSBA_OK;

@@ -70,6 +70,40 @@ def test_modified_cholesky_on_a_chosen_matrix(shift, problems, gpu):
         assert lam > 0
 
 
+@pytest.mark.parametrize("shift", [-3.0, -400.0, 0.0])
+def test_modified_cholesky_on_the_cooperative_grid(shift, problems, gpu, monkeypatch):
+    """k_cholmod_grid (the route of large S, forced here with PSBA_CHOLMOD_GRID=1) against the one-workgroup
+    kernel and the oracle's twin on one 324 x 324 matrix (54cams supplies the size): every sum is formed by one
+    thread in the same order on both routes, so delta, beta and the count of block columns on the one-column
+    route are equal and lambda differs by the summation order of the E_i only."""
+    prob = problems["54cams"]
+    gpu.upload_problem(prob)
+    n = 6 * int(prob["nC"])
+    n32 = gpu.chol_dist_shape()[0]
+    rng = np.random.default_rng(int(-shift) + 5)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T + shift * np.eye(n)
+    buf = np.zeros((n32 + 1, n32))
+    buf[:n, :n] = A
+    buf[n:n32, n:] = np.eye(n32 - n)
+    got = {}
+    for route in ("0", "1"):
+        monkeypatch.setenv("PSBA_CHOLMOD_GRID", route)
+        gpu.linearize(1.0, 1.0)
+        gpu.schur_assemble(1.0)
+        gpu.set_reduce_buffer(buf.reshape(-1))
+        got[route] = gpu.cholmod_lambda(reassemble=False)
+    (lam0, info0), (lam1, info1) = got["0"], got["1"]
+    assert info0[0] == info1[0] and info0[1] == info1[1] and info0[2] == info1[2]
+    L, E, delta, beta = cholmod(A)
+    want = abs(E.sum()) / n
+    scale = 1e-9 * want + 1e-13 * np.abs(A).max()
+    assert abs(lam1 - lam0) <= 1e-3 * scale + 1e-12 * abs(lam0)
+    assert abs(lam1 - want) <= scale
+    if shift < 0:
+        assert lam1 > 0 and info1[2] > 0  # the one-column route was taken
+
+
 def test_modified_cholesky_lambda_makes_S_positive_definite(problems, gpu):
     """S at lambda = 0 of 7cams is not positive definite (no gauge is fixed): the reference then
     estimates lambda from a modified Cholesky (trust_region.cpp:341-363).  The singular directions
