@@ -293,19 +293,20 @@ __global__ __launch_bounds__(CM_THREADS) void k_cholmod(double *M, int ld, int n
 // same arithmetic, same result everywhere, no broadcast) or kept in per-step slots that are zeroed
 // once before the launch and never reset (the "above beta" flags and the column maxima: a slot
 // per block column / column, so no workgroup can read a slot that another already reuses).
-// gs: [0..9) T_JJ | ov[nJ] ints | ov1[n] ints | th[n] u64 | part[gridDim.x] doubles (host layout below).
-constexpr int CMG_THREADS = 128;
+// gs: [0..9) spare | ov[nJ] ints | ov1[n] ints | th[n] u64 | part[gridDim.x] doubles (host layout below).
+constexpr int CMG_THREADS = 64;  // one wave per workgroup: up to 256 workgroups, one per CU
+constexpr int CMG_TILE = 1024;    // entries of the three L_J rows per LDS tile (24 KiB)
 
 __global__ __launch_bounds__(CMG_THREADS) void k_cholmod_grid(double *M, int ld, int n, double *aux, double *out,
                                                               double *gs) {
   namespace cg = cooperative_groups;
   cg::grid_group grid = cg::this_grid();
   __shared__ double sRed[CMG_THREADS / 64];
+  __shared__ double sLt[3][CMG_TILE];
   const int tid = threadIdx.x;
   const int gtid = blockIdx.x * CMG_THREADS + tid, GT = gridDim.x * CMG_THREADS;
   const int nJ = n / 3;
   double *C = aux, *bak = aux + n, *dg = aux + 4 * (size_t)n;
-  volatile double *T = gs;
   int *ov = reinterpret_cast<int *>(gs + 10);                       // [nJ + 1]
   int *ov1 = ov + (nJ + 2);                                          // [n]
   unsigned long long *th = reinterpret_cast<unsigned long long *>(gs + 10 + (nJ + 2 + n + 1) / 2 + 1);  // [n + 2]
@@ -344,22 +345,80 @@ __global__ __launch_bounds__(CMG_THREADS) void k_cholmod_grid(double *M, int ld,
   const double beta = sqrt(fmax(fmax(gamma, 1e-15), xi / sqrt((double)n * n - 1.0)));
   int single = 0;
   for (int J = 0; J + 3 <= n; J += 3) {
-    for (int r = J + gtid; r < n; r += GT)
+    // T_iJ = A_iJ - sum_k L_ik L_Jk^T for every row from J on -- the rows J .. J + 2 give T_JJ (cholmod_blk.cl:104-131),
+    // so no workgroup forms it alone while the others wait.  One thread per row, k ascending (the order of
+    // k_cholmod); the three rows of L_J come through the LDS in tiles, the thread's own row streams from memory
+    // two entries per load.  The column's original goes to bak, T into its place.
+    for (int base = J; base < n; base += GT) {
+      if (base + (int)blockIdx.x * CMG_THREADS >= n) break;  // (uniform over the workgroup)
+      const int i = base + gtid;
+      const bool live = i < n;
+      const double *Li = M + (size_t)(live ? i : J) * ld;
+      double t0 = Li[J], t1 = Li[J + 1], t2 = Li[J + 2];
+      if (live) {
+        bak[3 * (size_t)i] = t0;
+        bak[3 * (size_t)i + 1] = t1;
+        bak[3 * (size_t)i + 2] = t2;
+      }
+      for (int k0 = 0; k0 < J; k0 += CMG_TILE) {
+        const int len = J - k0 < CMG_TILE ? J - k0 : CMG_TILE;
+        __syncthreads();
+        for (int q = tid; q < 3 * len; q += CMG_THREADS) {
+          const int v = q / len, kk = q - v * len;
+          sLt[v][kk] = M[(size_t)(J + v) * ld + k0 + kk];
+        }
+        __syncthreads();
+        if (live) {
+          const double *row = Li + k0;
+          int kk = 0;
+          // four cache lines of the row per turn, all loads issued before the first product: a lane has one
+          // line in flight otherwise and the step is a chain of memory latencies (2.1 s at n = 12 000; 1.4 s
+          // so; with the next four lines requested before this turn's products -- two register buffers -- 2.9 s)
+          for (; kk + 64 <= len; kk += 64) {
+            double2 l[32];
 #pragma unroll
-      for (int c = 0; c < 3; c++) bak[3 * (size_t)r + c] = M[(size_t)r * ld + J + c];
-    if (blockIdx.x == 0 && tid < 9) {
-      const int u = tid / 3, v = tid % 3;
-      double t = M[(size_t)(J + u) * ld + J + v];
-      for (int k = 0; k < J; k++) t -= M[(size_t)(J + u) * ld + k] * M[(size_t)(J + v) * ld + k];
-      T[tid] = t;
+            for (int u = 0; u < 32; u++) l[u] = *reinterpret_cast<const double2 *>(row + kk + 2 * u);
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+              t0 -= l[u].x * sLt[0][kk + 2 * u];
+              t1 -= l[u].x * sLt[1][kk + 2 * u];
+              t2 -= l[u].x * sLt[2][kk + 2 * u];
+              t0 -= l[u].y * sLt[0][kk + 2 * u + 1];
+              t1 -= l[u].y * sLt[1][kk + 2 * u + 1];
+              t2 -= l[u].y * sLt[2][kk + 2 * u + 1];
+            }
+          }
+          for (; kk + 2 <= len; kk += 2) {
+            const double2 l = *reinterpret_cast<const double2 *>(row + kk);
+            t0 -= l.x * sLt[0][kk];
+            t1 -= l.x * sLt[1][kk];
+            t2 -= l.x * sLt[2][kk];
+            t0 -= l.y * sLt[0][kk + 1];
+            t1 -= l.y * sLt[1][kk + 1];
+            t2 -= l.y * sLt[2][kk + 1];
+          }
+          if (kk < len) {
+            const double lik = row[kk];
+            t0 -= lik * sLt[0][kk];
+            t1 -= lik * sLt[1][kk];
+            t2 -= lik * sLt[2][kk];
+          }
+        }
+      }
+      if (live) {
+        double *o = M + (size_t)i * ld + J;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+      }
     }
-    grid.sync();  // T_JJ is there (and nobody reads the previous one any more: those reads sit before the
-                  // previous step's second barrier)
+    grid.sync();
     // L_JJ L_JJ^T = T_JJ (:134-205), by every thread
     int fail = 0;
+    const volatile double *T = M + (size_t)J * ld + J;
     double l00 = T[0], l10 = 0, l11 = 0, l20 = 0, l21 = 0, l22 = 0;
     {
-      const double t3 = T[3], t4 = T[4], t6 = T[6], t7 = T[7], t8 = T[8];
+      const double t3 = T[ld], t4 = T[ld + 1], t6 = T[2 * (size_t)ld], t7 = T[2 * (size_t)ld + 1], t8 = T[2 * (size_t)ld + 2];
       if (!isfinite(l00) || l00 <= 0) fail = 1;
       if (!fail) {
         l00 = sqrt(l00);
@@ -379,20 +438,14 @@ __global__ __launch_bounds__(CMG_THREADS) void k_cholmod_grid(double *M, int ld,
     if (!fail) {  // (uniform over the grid: every thread factored the same nine numbers)
       int over = 0;
       for (int i = J + 3 + gtid; i < n; i += GT) {
-        double t0 = M[(size_t)i * ld + J], t1 = M[(size_t)i * ld + J + 1], t2 = M[(size_t)i * ld + J + 2];
-        const double *Li = M + (size_t)i * ld, *L0 = M + (size_t)J * ld, *L1 = L0 + ld, *L2 = L1 + ld;
-        for (int k = 0; k < J; k++) {
-          const double lik = Li[k];
-          t0 -= lik * L0[k];
-          t1 -= lik * L1[k];
-          t2 -= lik * L2[k];
-        }
+        double *o = M + (size_t)i * ld + J;
+        const double t0 = o[0], t1 = o[1], t2 = o[2];
         const double x0 = t0 / l00;
         const double x1 = (t1 - x0 * l10) / l11;
         const double x2 = (t2 - x0 * l20 - x1 * l21) / l22;
-        M[(size_t)i * ld + J] = x0;
-        M[(size_t)i * ld + J + 1] = x1;
-        M[(size_t)i * ld + J + 2] = x2;
+        o[0] = x0;
+        o[1] = x1;
+        o[2] = x2;
         if (x0 > beta || x1 > beta || x2 > beta) over = 1;
       }
       if (over) atomicOr(ov + J / 3, 1);
@@ -526,7 +579,7 @@ int launch_cholmod(psba_ctx *h, double *out4_dev) {
   const bool use_grid = force ? atoi(force) != 0 : n >= 1536;
   if (use_grid) {
     int nwg = (n + CMG_THREADS - 1) / CMG_THREADS;
-    if (nwg > 256) nwg = 256;  // one workgroup of 128 threads per CU at most: co-resident by a wide margin
+    if (nwg > 256) nwg = 256;  // one wave per CU at most: co-resident by a wide margin
     const int nJ = n / 3;
     double *gs = aux + 5 * (size_t)n;
     const size_t gs_doubles = 10 + (size_t)(nJ + 2 + n + 1) / 2 + 1 + (n + 2) + nwg;
