@@ -573,10 +573,11 @@ int launch_cholmod(psba_ctx *h, double *out4_dev) {
   double *M = h->chol_L, *aux = h->chol_L + (size_t)(h->n32 + 1) * ld;  // 5 n <= (n32 + 15) * n32 doubles of room
   if ((size_t)5 * n > (size_t)(h->n32 + 15) * ld) return fail(h, PSBA_E_INVALID, "cholmod scratch too small");
   PSBA_HIP(h, hipMemcpyAsync(M, h->red, sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, h->stream));
-  // large S: the cooperative grid (one workgroup needs minutes at n = 12 000); PSBA_CHOLMOD_GRID=1 / 0 forces
-  // either (the tests run the small problems through both and compare)
+  // the cooperative grid from 50 cameras on (one workgroup against the grid, assembly included: 4.1 / 2.0 ms at
+  // n = 324, 16.7 / 5.1 at 600, 98 / 15.9 at 1200, 323 / 35 at 1800, minutes / 1.4 s at 12 000; not measured
+  // below); PSBA_CHOLMOD_GRID=1 / 0 forces either (the tests run one matrix through both and compare)
   const char *force = getenv("PSBA_CHOLMOD_GRID");
-  const bool use_grid = force ? atoi(force) != 0 : n >= 1536;
+  const bool use_grid = force ? atoi(force) != 0 : n >= 300;
   if (use_grid) {
     int nwg = (n + CMG_THREADS - 1) / CMG_THREADS;
     if (nwg > 256) nwg = 256;  // one wave per CU at most: co-resident by a wide margin

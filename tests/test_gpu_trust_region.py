@@ -172,6 +172,9 @@ def test_trust_region_steps_at_a_given_damping(name, problems, gpu):
     res, _ = gpu.levmar(max_iter=50, tr_handoff=True)
     tr, log = gpu.trust_region(start_itno=res.iters, init_lambda=lam)
     acc, oacc = log[log[:, 5] > 0], olog[olog[:, 5] > 0]
+    # (shown when the test fails: the try whose gain ratio or status differs is the thing to look at)
+    print("LM here / oracle: iters", res.iters, ores.iters, "tries", res.tries, ores.tries, "final", res.final_err, ores.final_err)
+    print("TR log here (itno, cost, rho, delta, lambda, accepted):\n", log[:10], "\nTR log of the oracle:\n", olog[:10])
     # the steps before the loop resets lambda to 0 (ten good steps in a row, trust_region.cpp:266-271;
     # the factorization after that fails again and the paths part as in the test above)
     n = min(len(acc), len(oacc), 6, int(np.argmax(oacc[:, 4] != lam)) if (oacc[:, 4] != lam).any() else len(oacc))
